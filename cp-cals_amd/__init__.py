@@ -1,0 +1,274 @@
+"""cp-cals_amd: MI355X-native Concurrent-ALS (CALS) hot path.
+
+Python is only the test/bench harness here: this module is a thin ctypes binding of the C ABI in
+include/cals_hip.h (libcals_hip.so, hand-written HIP for gfx950).  There is no CPU fallback: if the
+shared library is missing or no gfx950 device is visible, construction fails loudly.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcals_hip.so")
+MAX_MODES = 8
+MAX_RANK = 32
+
+OK, ERR_ARG, ERR_HIP, ERR_STATE, ERR_FULL, ERR_NO_DEVICE = 0, 1, 2, 3, 4, 5
+
+
+class CalsHipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("cals_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+class Params(C.Structure):
+    """CalsParams fields that steer the loop (reference include/cals.h:138-159)."""
+    _fields_ = [
+        ("max_iterations", C.c_int64), ("tol", C.c_double), ("line_search", C.c_int),
+        ("line_search_interval", C.c_int), ("line_search_step", C.c_double),
+        ("line_search_method", C.c_int), ("force_max_iter", C.c_int),
+        ("always_evict_first", C.c_int),
+    ]
+
+
+class Report(C.Structure):
+    _fields_ = [
+        ("iter", C.c_int64), ("n_ktensors", C.c_int64), ("ktensor_comp_sum", C.c_int64),
+        ("ls_performed", C.c_int64), ("ls_failed", C.c_int64), ("X_norm", C.c_double),
+        ("total_ms", C.c_double), ("loop_ms", C.c_double),
+    ]
+
+
+class ModelStatus(C.Structure):
+    _fields_ = [("iters", C.c_int64), ("fit", C.c_double), ("old_fit", C.c_double),
+                ("approx_error", C.c_double), ("evicted", C.c_int)]
+
+
+class KernelStats(C.Structure):
+    _fields_ = [
+        ("mttkrp_launches", C.c_int64), ("mttkrp_ms", C.c_double), ("mttkrp_flops", C.c_double),
+        ("update_launches", C.c_int64), ("update_ms", C.c_double),
+        ("other_launches", C.c_int64), ("other_ms", C.c_double),
+    ]
+
+
+EXPORTS = [
+    "cals_hip_default_params", "cals_hip_create", "cals_hip_destroy", "cals_hip_last_error",
+    "cals_hip_set_tensor", "cals_hip_set_params", "cals_hip_enqueue", "cals_hip_run",
+    "cals_hip_model_result", "cals_hip_admit", "cals_hip_sweep", "cals_hip_evict",
+    "cals_hip_active_cols", "cals_hip_models_in_flight", "cals_hip_queue_size",
+    "cals_hip_synchronize", "cals_hip_debug_mttkrp", "cals_hip_debug_get_factor",
+    "cals_hip_debug_get_lambda", "cals_hip_debug_get_gramian", "cals_hip_debug_model_status",
+    "cals_hip_debug_get_norms", "cals_hip_set_profiling", "cals_hip_get_kernel_stats",
+    "cals_hip_reset_kernel_stats", "cals_hip_stream", "cals_hip_device_count",
+]
+
+_LIB = None
+
+
+def load_library():
+    """dlopen libcals_hip.so (no GPU needed for this step); raises if it is missing."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise CalsHipError(ERR_NO_DEVICE, "%s not built (run __graft_entry__.build()); the engine "
+                           "has no CPU fallback" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    vp, i64, dp = C.c_void_p, C.c_int64, C.POINTER(C.c_double)
+    lib.cals_hip_create.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(i64), i64, C.c_int]
+    lib.cals_hip_destroy.argtypes = [vp]
+    lib.cals_hip_last_error.argtypes = [vp]
+    lib.cals_hip_last_error.restype = C.c_char_p
+    lib.cals_hip_set_tensor.argtypes = [vp, dp]
+    lib.cals_hip_set_params.argtypes = [vp, C.POINTER(Params)]
+    lib.cals_hip_enqueue.argtypes = [vp, i64, C.POINTER(dp), dp, C.c_int, i64, C.POINTER(i64)]
+    lib.cals_hip_run.argtypes = [vp, C.POINTER(Report)]
+    lib.cals_hip_model_result.argtypes = [vp, i64, C.POINTER(ModelStatus)]
+    lib.cals_hip_admit.argtypes = [vp, C.POINTER(i64)]
+    lib.cals_hip_sweep.argtypes = [vp, i64]
+    lib.cals_hip_evict.argtypes = [vp, C.POINTER(i64)]
+    for f in ("cals_hip_active_cols", "cals_hip_models_in_flight", "cals_hip_queue_size"):
+        getattr(lib, f).argtypes = [vp]
+        getattr(lib, f).restype = i64
+    lib.cals_hip_synchronize.argtypes = [vp]
+    lib.cals_hip_debug_mttkrp.argtypes = [vp, C.c_int, dp]
+    lib.cals_hip_debug_get_factor.argtypes = [vp, C.c_int, dp]
+    lib.cals_hip_debug_get_lambda.argtypes = [vp, dp]
+    lib.cals_hip_debug_get_gramian.argtypes = [vp, C.c_int, dp]
+    lib.cals_hip_debug_model_status.argtypes = [vp, i64, C.POINTER(ModelStatus), C.POINTER(i64)]
+    lib.cals_hip_debug_get_norms.argtypes = [vp, dp, dp]
+    lib.cals_hip_set_profiling.argtypes = [vp, C.c_int]
+    lib.cals_hip_get_kernel_stats.argtypes = [vp, C.POINTER(KernelStats)]
+    lib.cals_hip_reset_kernel_stats.argtypes = [vp]
+    lib.cals_hip_stream.argtypes = [vp]
+    lib.cals_hip_stream.restype = vp
+    lib.cals_hip_device_count.restype = C.c_int
+    _LIB = lib
+    return lib
+
+
+def default_params(**kw):
+    p = Params()
+    load_library().cals_hip_default_params(C.byref(p))
+    for k, v in kw.items():
+        if not hasattr(p, k):
+            raise AttributeError(k)
+        setattr(p, k, v)
+    return p
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+class Model:
+    """Host-side Ktensor handed to the engine: col-major factors + lambda (+ jk).  The arrays are
+    overwritten with the fitted model when the engine evicts it."""
+
+    def __init__(self, factors, lam, jk=None):
+        self.factors = [np.asfortranarray(np.array(f, dtype=np.float64, order="F")) for f in factors]
+        self.rank = int(self.factors[0].shape[1])
+        self.lam = np.array(lam, dtype=np.float64)
+        self.jk = jk
+        self.ticket = -1
+        self.iters = 0
+        self.fit = self.old_fit = self.error = 0.0
+
+
+class Engine:
+    """One CALS engine on one GPU (cals_hip_engine)."""
+
+    def __init__(self, modes, buffer_size, device=0):
+        self.lib = load_library()
+        self.modes = [int(m) for m in modes]
+        self.h = C.c_void_p()
+        arr = (C.c_int64 * len(self.modes))(*self.modes)
+        rc = self.lib.cals_hip_create(C.byref(self.h), len(self.modes), arr, int(buffer_size), int(device))
+        if rc != OK:
+            msg = self.lib.cals_hip_last_error(self.h).decode() if self.h else "create failed"
+            if self.h:
+                self.lib.cals_hip_destroy(self.h)
+                self.h = C.c_void_p()
+            raise CalsHipError(rc, msg)
+        self._models = []
+
+    def _chk(self, rc):
+        if rc != OK:
+            raise CalsHipError(rc, self.lib.cals_hip_last_error(self.h).decode())
+
+    def close(self):
+        if self.h:
+            self.lib.cals_hip_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_tensor(self, X):
+        Xf = np.ascontiguousarray(np.asarray(X, dtype=np.float64).ravel())
+        assert Xf.size == int(np.prod(self.modes))
+        self._chk(self.lib.cals_hip_set_tensor(self.h, _dp(Xf)))
+
+    def set_params(self, params):
+        self._chk(self.lib.cals_hip_set_params(self.h, C.byref(params)))
+
+    def enqueue(self, model):
+        ptrs = (C.POINTER(C.c_double) * len(self.modes))(*[_dp(f) for f in model.factors])
+        t = C.c_int64(-1)
+        jm = -1 if model.jk is None else int(model.jk[0])
+        jf = 0 if model.jk is None else int(model.jk[1])
+        self._chk(self.lib.cals_hip_enqueue(self.h, model.rank, ptrs, _dp(model.lam), jm, jf, C.byref(t)))
+        model.ticket = t.value
+        self._models.append(model)  # keep the arrays alive
+        return t.value
+
+    def run(self):
+        rep = Report()
+        self._chk(self.lib.cals_hip_run(self.h, C.byref(rep)))
+        for m in self._models:
+            self.result(m)
+        return rep
+
+    def result(self, model):
+        st = ModelStatus()
+        self._chk(self.lib.cals_hip_model_result(self.h, model.ticket, C.byref(st)))
+        model.iters, model.fit, model.old_fit, model.error = st.iters, st.fit, st.old_fit, st.approx_error
+        return st
+
+    def admit(self):
+        n = C.c_int64(0)
+        self._chk(self.lib.cals_hip_admit(self.h, C.byref(n)))
+        return n.value
+
+    def sweep(self, n=1):
+        self._chk(self.lib.cals_hip_sweep(self.h, int(n)))
+
+    def evict(self):
+        n = C.c_int64(0)
+        self._chk(self.lib.cals_hip_evict(self.h, C.byref(n)))
+        return n.value
+
+    def synchronize(self):
+        self._chk(self.lib.cals_hip_synchronize(self.h))
+
+    @property
+    def active_cols(self):
+        return self.lib.cals_hip_active_cols(self.h)
+
+    @property
+    def models_in_flight(self):
+        return self.lib.cals_hip_models_in_flight(self.h)
+
+    def debug_mttkrp(self, mode):
+        R = self.active_cols
+        G = np.zeros((self.modes[mode], R), order="F")
+        self._chk(self.lib.cals_hip_debug_mttkrp(self.h, int(mode), _dp(G)))
+        return G
+
+    def debug_factor(self, mode):
+        F = np.zeros((self.modes[mode], self.active_cols), order="F")
+        self._chk(self.lib.cals_hip_debug_get_factor(self.h, int(mode), _dp(F)))
+        return F
+
+    def debug_lambda(self):
+        lam = np.zeros(self.active_cols)
+        self._chk(self.lib.cals_hip_debug_get_lambda(self.h, _dp(lam)))
+        return lam
+
+    def debug_gramian(self, mode):
+        G = np.zeros((MAX_RANK, self.active_cols), order="F")
+        self._chk(self.lib.cals_hip_debug_get_gramian(self.h, int(mode), _dp(G)))
+        return G
+
+    def debug_status(self, model):
+        st = ModelStatus()
+        col = C.c_int64(-1)
+        self._chk(self.lib.cals_hip_debug_model_status(self.h, model.ticket, C.byref(st), C.byref(col)))
+        return st, col.value
+
+    def debug_norms(self):
+        xn = C.c_double(0)
+        jk = np.zeros(self.modes[0])
+        self._chk(self.lib.cals_hip_debug_get_norms(self.h, C.byref(xn), _dp(jk)))
+        return xn.value, jk
+
+    def set_profiling(self, on):
+        self._chk(self.lib.cals_hip_set_profiling(self.h, 1 if on else 0))
+
+    def kernel_stats(self):
+        ks = KernelStats()
+        self._chk(self.lib.cals_hip_get_kernel_stats(self.h, C.byref(ks)))
+        return ks
+
+    def reset_kernel_stats(self):
+        self._chk(self.lib.cals_hip_reset_kernel_stats(self.h))
+
+    @property
+    def stream(self):
+        return self.lib.cals_hip_stream(self.h)

@@ -1,0 +1,43 @@
+"""Build recipe of libcals_hip.so (hipcc, gfx950 only).  Used by __graft_entry__.build()."""
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libcals_hip.so")
+SOURCES = ["mttkrp_kernel.hip", "model_kernels.hip", "cals_hip_engine.cpp"]
+HEADERS = ["cals_hip_internal.h", os.path.join("..", "..", "include", "cals_hip.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result"]
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objs = []
+    hdrs = [os.path.join(CSRC, h) for h in HEADERS]
+    os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
+    for s in SOURCES:
+        src = os.path.join(CSRC, s)
+        obj = os.path.join(HERE, "build", os.path.splitext(s)[0] + ".o")
+        if force or _newer(obj, [src] + hdrs):
+            cmd = [hipcc] + FLAGS + ["-x", "hip", "-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+        objs.append(obj)
+    if force or _newer(LIB, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(verbose=True))

@@ -1,0 +1,1023 @@
+// C-ABI engine of the MI355X-native CALS hot path (include/cals_hip.h).
+//
+// Host side of the reference's cp_cals loop (src/cals.cpp:174-382) and of MultiKtensor
+// (src/multi_ktensor.cpp): queue, first-fit column allocator, registry, eviction, compress.
+// All numeric state lives on the device for the whole run: X (one padded permuted copy per
+// mode), the multi-factor buffers, per-model Gramians, lambda, errors, line-search copies.
+// The host sees only a few scalars per model per sweep.  There is no CPU fallback: if HIP is
+// unavailable every entry point fails with CALS_HIP_ERR_NO_DEVICE / CALS_HIP_ERR_HIP.
+#include "../../include/cals_hip.h"
+#include "cals_hip_internal.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <deque>
+#include <string>
+#include <vector>
+
+using namespace calship;
+
+namespace {
+
+struct HostModel {
+  int64_t rank = 0;
+  std::vector<double *> factors;  // caller's storage (in/out)
+  double *lambda = nullptr;
+  int jk_mode = -1;
+  int64_t jk_fiber = 0;
+  int state = 0;  // 0 queued, 1 in flight, 2 evicted
+  int slot = -1;
+  int64_t col = -1;
+  int64_t id = 0;  // MultiKtensor unique_kt_id
+  cals_hip_model_status st{};
+};
+
+struct ModeLayout {
+  int a_mode = -1;
+  std::vector<int> s_modes;
+  int A = 0, Ap = 0, Mp = 0;
+  long long S = 1;
+  double *Xp = nullptr;
+  int MT = 0, m_blocks = 1, ldPart = 0;
+};
+
+struct EventPair {
+  hipEvent_t a, b;
+};
+
+double now_ms() {
+  return std::chrono::duration<double, std::milli>(
+             std::chrono::steady_clock::now().time_since_epoch())
+      .count();
+}
+
+}  // namespace
+
+struct cals_hip_engine {
+  int n_modes = 0;
+  int64_t modes[CALS_HIP_MAX_MODES] = {0};
+  int64_t buffer = 0;
+  int device = 0;
+  int n_cu = 256;
+  hipStream_t stream = nullptr;
+  std::string err;
+  cals_hip_params prm{};
+
+  bool has_tensor = false;
+  double X_norm = 0.0;
+  double *d_jk_norms = nullptr;
+  std::vector<double> jk_norms;
+  ModeLayout lay[CALS_HIP_MAX_MODES];
+
+  double *factor[CALS_HIP_MAX_MODES] = {nullptr};
+  double *prev[CALS_HIP_MAX_MODES] = {nullptr};
+  double *backup[CALS_HIP_MAX_MODES] = {nullptr};
+  double *gram[CALS_HIP_MAX_MODES] = {nullptr};
+  double *lambda = nullptr, *prev_lambda = nullptr, *backup_lambda = nullptr;
+  bool ls_allocated = false;
+  double *partial = nullptr;
+  size_t partial_elems = 0;
+  double *krp_ws = nullptr;
+  size_t krp_elems = 0;
+
+  ModelTable mt{};
+  int max_slots = 0;
+  int *d_slots = nullptr;
+  bool slots_dirty = true;
+  std::vector<int> free_slots;
+
+  // host mirrors of the per-slot scalars (filled by fetch_status)
+  std::vector<int> h_flags;
+  std::vector<long long> h_iters;
+  std::vector<double> h_err, h_fit, h_old_fit;
+
+  std::vector<HostModel> models;   // by ticket
+  std::deque<int64_t> queue;       // tickets
+  std::vector<int64_t> registry;   // tickets of in-flight models, ascending id (std::map order)
+  std::vector<int64_t> occ;        // occupancy_vec: id per column, 0 = free
+  int64_t unique_id = 1;
+  int64_t end = 1;                 // active columns (adjust_edges)
+  bool flag_jk = false;
+
+  // report counters
+  int64_t n_ktensors = 0, comp_sum = 0, ls_performed = 0, ls_failed = 0, sweeps = 0;
+
+  // profiling
+  bool profiling = false;
+  std::vector<EventPair> ev_pool;
+  size_t ev_used = 0;
+  struct Rec {
+    int cls;  // 0 mttkrp, 1 update, 2 other
+    size_t ev;
+    double flops;
+  };
+  std::vector<Rec> recs;
+  cals_hip_kernel_stats stats{};
+};
+
+namespace {
+
+int fail(cals_hip_engine *e, int code, const std::string &msg) {
+  if (e) e->err = msg;
+  return code;
+}
+
+#define HIPCHK(call)                                                                        \
+  do {                                                                                      \
+    hipError_t _e = (call);                                                                 \
+    if (_e != hipSuccess)                                                                   \
+      return fail(e, CALS_HIP_ERR_HIP,                                                      \
+                  std::string(#call) + ": " + hipGetErrorString(_e) + " (" __FILE__ ":" +   \
+                      std::to_string(__LINE__) + ")");                                      \
+  } while (0)
+
+int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+template <typename T>
+int dev_alloc(cals_hip_engine *e, T **p, size_t n) {
+  HIPCHK(hipMalloc((void **)p, std::max<size_t>(n, 1) * sizeof(T)));
+  HIPCHK(hipMemsetAsync(*p, 0, std::max<size_t>(n, 1) * sizeof(T), e->stream));
+  return CALS_HIP_OK;
+}
+
+// MultiKtensor::adjust_edges, src/multi_ktensor.cpp:165-186 (cell 0 is never examined)
+void adjust_edges(cals_hip_engine *e) {
+  int64_t end = e->buffer;
+  for (int64_t i = end - 1; i > 0; i--) {
+    if (e->occ[i] == 0)
+      end--;
+    else
+      break;
+  }
+  e->end = end;
+}
+
+// MultiKtensor::check_availability, src/multi_ktensor.cpp:14-39
+int64_t check_availability(const cals_hip_engine *e, int64_t rank) {
+  int64_t comp_counter = 0, pos_index = -1, prev_occ = -1;
+  for (int64_t i = 0; i < e->buffer; i++) {
+    if (comp_counter == rank) break;
+    if (e->occ[i] == 0 && prev_occ != 0) {
+      pos_index = i;
+      comp_counter++;
+    } else if (e->occ[i] == 0 && prev_occ == 0)
+      comp_counter++;
+    else
+      comp_counter = 0;
+    prev_occ = e->occ[i];
+  }
+  if (pos_index == -1 || comp_counter != rank) return -1;
+  return pos_index;
+}
+
+// ---- profiling helpers ----
+int prof_begin(cals_hip_engine *e, int cls, double flops) {
+  if (!e->profiling) return -1;
+  if (e->ev_used >= e->ev_pool.size()) {
+    if (e->ev_pool.size() >= 16384) return -1;
+    EventPair p;
+    if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return -1;
+    e->ev_pool.push_back(p);
+  }
+  const size_t k = e->ev_used++;
+  (void)hipEventRecord(e->ev_pool[k].a, e->stream);
+  e->recs.push_back({cls, k, flops});
+  return (int)k;
+}
+void prof_end(cals_hip_engine *e, int k) {
+  if (k >= 0) (void)hipEventRecord(e->ev_pool[k].b, e->stream);
+}
+void prof_collect(cals_hip_engine *e) {
+  if (e->recs.empty()) return;
+  (void)hipStreamSynchronize(e->stream);
+  for (auto &r : e->recs) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, e->ev_pool[r.ev].a, e->ev_pool[r.ev].b) != hipSuccess) continue;
+    if (r.cls == 0) {
+      e->stats.mttkrp_launches++;
+      e->stats.mttkrp_ms += ms;
+      e->stats.mttkrp_flops += r.flops;
+    } else if (r.cls == 1) {
+      e->stats.update_launches++;
+      e->stats.update_ms += ms;
+    } else {
+      e->stats.other_launches++;
+      e->stats.other_ms += ms;
+    }
+  }
+  e->recs.clear();
+  e->ev_used = 0;
+}
+
+int upload_slots(cals_hip_engine *e) {
+  if (!e->slots_dirty) return CALS_HIP_OK;
+  std::vector<int> s;
+  s.reserve(e->registry.size());
+  for (auto t : e->registry) s.push_back(e->models[t].slot);
+  if (!s.empty()) {
+    HIPCHK(hipMemcpyAsync(e->d_slots, s.data(), s.size() * sizeof(int), hipMemcpyHostToDevice,
+                          e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));  // s is a temporary
+  }
+  e->slots_dirty = false;
+  return CALS_HIP_OK;
+}
+
+int alloc_ls(cals_hip_engine *e) {
+  if (e->ls_allocated) return CALS_HIP_OK;
+  for (int n = 0; n < e->n_modes; n++) {
+    int rc;
+    if ((rc = dev_alloc(e, &e->prev[n], (size_t)(e->modes[n] * e->buffer)))) return rc;
+    if ((rc = dev_alloc(e, &e->backup[n], (size_t)(e->modes[n] * e->buffer)))) return rc;
+  }
+  int rc;
+  if ((rc = dev_alloc(e, &e->prev_lambda, (size_t)e->buffer))) return rc;
+  if ((rc = dev_alloc(e, &e->backup_lambda, (size_t)e->buffer))) return rc;
+  e->ls_allocated = true;
+  return CALS_HIP_OK;
+}
+
+// MTTKRP launch geometry for `mode` at R active columns
+struct Geo {
+  int NB, T;
+};
+Geo geometry(const cals_hip_engine *e, int mode, int64_t R) {
+  const ModeLayout &L = e->lay[mode];
+  Geo g;
+  g.NB = (int)((R + CALS_BN - 1) / CALS_BN);
+  const long long U = (long long)(L.Ap / 16) * L.S;
+  long long T = e->n_cu / std::max(1, g.NB * L.m_blocks);
+  if (T < 1) T = 1;
+  if (T > U) T = U;
+  g.T = (int)T;
+  return g;
+}
+
+int launch_mttkrp(cals_hip_engine *e, int mode, int64_t R, Geo *geo_out) {
+  const ModeLayout &L = e->lay[mode];
+  const Geo g = geometry(e, mode, R);
+  const double *Q;
+  long long ldQ;
+  if (L.s_modes.size() == 1) {
+    Q = e->factor[L.s_modes[0]];
+    ldQ = e->modes[L.s_modes[0]];
+  } else {
+    KrpArgs k{};
+    k.n = (int)L.s_modes.size();
+    for (int i = 0; i < k.n; i++) {
+      k.F[i] = e->factor[L.s_modes[i]];
+      k.ld[i] = e->modes[L.s_modes[i]];
+      k.dims[i] = (int)e->modes[L.s_modes[i]];
+    }
+    k.S = L.S;
+    k.R = (int)R;
+    k.Q = e->krp_ws;
+    const int pk = prof_begin(e, 2, 0);
+    HIPCHK(krp_launch(k, e->stream));
+    prof_end(e, pk);
+    Q = e->krp_ws;
+    ldQ = L.S;
+  }
+  MttkrpArgs a{};
+  a.Xp = L.Xp;
+  a.P = e->factor[L.a_mode];
+  a.ldP = e->modes[L.a_mode];
+  a.Q = Q;
+  a.ldQ = ldQ;
+  a.partial = e->partial;
+  a.S = L.S;
+  a.Mp = L.Mp;
+  a.Ap = L.Ap;
+  a.A = L.A;
+  a.R = (int)R;
+  a.NB = g.NB;
+  a.T = g.T;
+  a.ldPart = L.ldPart;
+  a.grid = g.NB * g.T;
+  if ((size_t)a.grid * (size_t)L.ldPart * CALS_BN > e->partial_elems)
+    return fail(e, CALS_HIP_ERR_STATE, "internal: partial buffer too small");
+  double total = 1.0;
+  for (int n = 0; n < e->n_modes; n++) total *= (double)e->modes[n];
+  const int pk = prof_begin(e, 0, 2.0 * total * (double)R);
+  HIPCHK(mttkrp_launch(L.MT, L.m_blocks, a, e->stream));
+  prof_end(e, pk);
+  if (geo_out) *geo_out = g;
+  return CALS_HIP_OK;
+}
+
+LsArgs make_ls_args(cals_hip_engine *e) {
+  LsArgs a{};
+  a.slots = e->d_slots;
+  a.n_slots = (int)e->registry.size();
+  a.mt = e->mt;
+  for (int n = 0; n < e->n_modes; n++) {
+    a.factor[n] = e->factor[n];
+    a.prev[n] = e->prev[n];
+    a.backup[n] = e->backup[n];
+    a.I[n] = (int)e->modes[n];
+    a.gram[n] = e->gram[n];
+  }
+  a.lambda = e->lambda;
+  a.prev_lambda = e->prev_lambda;
+  a.backup_lambda = e->backup_lambda;
+  a.n_modes = e->n_modes;
+  a.interval = e->prm.line_search_interval;
+  a.step = e->prm.line_search_step;
+  a.max_iter = e->prm.max_iterations;
+  return a;
+}
+
+// One sweep over the modes for all in-flight models (src/cals.cpp:203-331) + finish kernel.
+int sweep_once(cals_hip_engine *e, bool evict_enabled) {
+  if (e->registry.empty()) return CALS_HIP_OK;
+  int rc = upload_slots(e);
+  if (rc) return rc;
+  const int64_t R = e->end;
+  const int ns = (int)e->registry.size();
+  if (e->prm.line_search) {
+    if ((rc = alloc_ls(e))) return rc;
+    LsArgs la = make_ls_args(e);
+    const int pk = prof_begin(e, 2, 0);
+    HIPCHK(ls_snapshot_launch(la, e->stream));
+    prof_end(e, pk);
+  }
+  for (int n = 0; n < e->n_modes; n++) {
+    Geo g;
+    if ((rc = launch_mttkrp(e, n, R, &g))) return rc;
+    UpdateArgs u{};
+    u.slots = e->d_slots;
+    u.n_slots = ns;
+    u.mt = e->mt;
+    u.factor = e->factor[n];
+    u.I = (int)e->modes[n];
+    u.partial = e->partial;
+    u.NB = g.NB;
+    u.T = g.T;
+    u.ldPart = e->lay[n].ldPart;
+    for (int m = 0; m < e->n_modes; m++) u.gram[m] = e->gram[m];
+    u.lambda = e->lambda;
+    u.n_modes = e->n_modes;
+    u.mode = n;
+    u.is_last = (n == e->n_modes - 1);
+    u.X_norm = e->X_norm;
+    u.jk_norms = e->d_jk_norms;
+    const int pk = prof_begin(e, 1, 0);
+    HIPCHK(update_launch(u, CALS_RMAX, e->stream));
+    prof_end(e, pk);
+  }
+  if (e->prm.line_search) {
+    LsArgs la = make_ls_args(e);
+    const int pk = prof_begin(e, 2, 0);
+    HIPCHK(ls_launch(la, e->stream));
+    prof_end(e, pk);
+  }
+  if (!e->prm.always_evict_first || !evict_enabled) {
+    FinishArgs f{};
+    f.slots = e->d_slots;
+    f.n_slots = ns;
+    f.mt = e->mt;
+    f.max_iter = e->prm.max_iterations;
+    f.tol = e->prm.tol;
+    f.force_max_iter = e->prm.force_max_iter;
+    f.evict_enabled = evict_enabled ? 1 : 0;
+    const int pk = prof_begin(e, 2, 0);
+    HIPCHK(finish_launch(f, e->stream));
+    prof_end(e, pk);
+  }
+  e->sweeps++;
+  return CALS_HIP_OK;
+}
+
+int fetch_status(cals_hip_engine *e) {
+  const size_t n = (size_t)e->max_slots;
+  HIPCHK(hipMemcpyAsync(e->h_flags.data(), e->mt.flags, n * sizeof(int), hipMemcpyDeviceToHost,
+                        e->stream));
+  HIPCHK(hipMemcpyAsync(e->h_iters.data(), e->mt.iters, n * sizeof(long long),
+                        hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipMemcpyAsync(e->h_err.data(), e->mt.err, n * sizeof(double), hipMemcpyDeviceToHost,
+                        e->stream));
+  HIPCHK(hipMemcpyAsync(e->h_fit.data(), e->mt.fit, n * sizeof(double), hipMemcpyDeviceToHost,
+                        e->stream));
+  HIPCHK(hipMemcpyAsync(e->h_old_fit.data(), e->mt.old_fit, n * sizeof(double),
+                        hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return CALS_HIP_OK;
+}
+
+// MultiKtensor::remove + Ktensor::detach (multi_ktensor.cpp:132-163, ktensor.cpp:127-135):
+// copy the model's columns back to the caller, zero them on the device, free the columns.
+int remove_model(cals_hip_engine *e, int64_t ticket) {
+  HostModel &m = e->models[ticket];
+  const int64_t r = m.rank;
+  for (int n = 0; n < e->n_modes; n++) {
+    const size_t bytes = sizeof(double) * (size_t)(e->modes[n] * r);
+    double *src = e->factor[n] + e->modes[n] * m.col;
+    HIPCHK(hipMemcpyAsync(m.factors[n], src, bytes, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemsetAsync(src, 0, bytes, e->stream));
+  }
+  HIPCHK(hipMemcpyAsync(m.lambda, e->lambda + m.col, sizeof(double) * (size_t)r,
+                        hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  m.st.iters = e->h_iters[m.slot];
+  m.st.approx_error = e->h_err[m.slot];
+  m.st.fit = e->h_fit[m.slot];
+  m.st.old_fit = e->h_old_fit[m.slot];
+  m.st.evicted = 1;
+  m.state = 2;
+  for (auto &c : e->occ)
+    if (c == m.id) c = 0;
+  e->free_slots.push_back(m.slot);
+  e->registry.erase(std::find(e->registry.begin(), e->registry.end(), ticket));
+  e->slots_dirty = true;
+  adjust_edges(e);
+  return CALS_HIP_OK;
+}
+
+// MultiKtensor::compress, src/multi_ktensor.cpp:188-264
+int compress(cals_hip_engine *e) {
+  int64_t col_offset = 0, added = -1;
+  std::vector<std::pair<int64_t, int64_t>> req;
+  for (int64_t c = 0; c < e->buffer; c++) {
+    const int64_t cell = e->occ[c];
+    if (cell == added)
+      continue;
+    else if (cell == 0)
+      col_offset++;
+    else if (col_offset != 0) {
+      req.emplace_back(cell, col_offset);
+      added = cell;
+    }
+  }
+  if (req.empty()) {
+    adjust_edges(e);
+    return CALS_HIP_OK;
+  }
+  for (auto &rq : req) {
+    HostModel *m = nullptr;
+    for (auto t : e->registry)
+      if (e->models[t].id == rq.first) m = &e->models[t];
+    if (!m) return fail(e, CALS_HIP_ERR_STATE, "internal: compress lost a model");
+    const int64_t off = rq.second, r = m->rank, col = m->col;
+    for (int n = 0; n < e->n_modes; n++) {
+      HIPCHK(move_columns_launch(e->factor[n], e->modes[n], col, r, off, e->stream));
+      HIPCHK(move_columns_launch(e->gram[n], CALS_RMAX, col, r, off, e->stream));
+      if (e->ls_allocated) {
+        HIPCHK(move_columns_launch(e->prev[n], e->modes[n], col, r, off, e->stream));
+        HIPCHK(move_columns_launch(e->backup[n], e->modes[n], col, r, off, e->stream));
+      }
+    }
+    HIPCHK(move_columns_launch(e->lambda, 1, col, r, off, e->stream));
+    if (e->ls_allocated) {
+      HIPCHK(move_columns_launch(e->prev_lambda, 1, col, r, off, e->stream));
+      HIPCHK(move_columns_launch(e->backup_lambda, 1, col, r, off, e->stream));
+    }
+    for (int64_t i = col; i < col + r; i++) std::swap(e->occ[i - off], e->occ[i]);
+    m->col -= off;
+    const int c32 = (int)m->col;
+    HIPCHK(hipMemcpyAsync(e->mt.col + m->slot, &c32, sizeof(int), hipMemcpyHostToDevice,
+                          e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+  }
+  adjust_edges(e);
+  return CALS_HIP_OK;
+}
+
+int admit(cals_hip_engine *e, int64_t *n_admitted) {
+  int64_t count = 0;
+  std::vector<int> new_slots;
+  while (!e->queue.empty()) {
+    const int64_t ticket = e->queue.front();
+    HostModel &m = e->models[ticket];
+    const int64_t pos = check_availability(e, m.rank);
+    if (pos < 0) break;  // BufferFull
+    if (e->free_slots.empty()) return fail(e, CALS_HIP_ERR_STATE, "internal: no free slot");
+    m.slot = e->free_slots.back();
+    e->free_slots.pop_back();
+    m.col = pos;
+    m.id = e->unique_id++;
+    m.state = 1;
+    for (int64_t i = 0; i < m.rank; i++) e->occ[pos + i] = m.id;
+    // Ktensor::attach: copy the model's factors into the buffer columns
+    for (int n = 0; n < e->n_modes; n++)
+      HIPCHK(hipMemcpyAsync(e->factor[n] + e->modes[n] * pos, m.factors[n],
+                            sizeof(double) * (size_t)(e->modes[n] * m.rank),
+                            hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(e->lambda + pos, m.lambda, sizeof(double) * (size_t)m.rank,
+                          hipMemcpyHostToDevice, e->stream));
+    // per-slot scalars
+    const int col32 = (int)pos, rank32 = (int)m.rank, jm = m.jk_mode, jf = (int)m.jk_fiber;
+    const long long one = 1;
+    const int zero = 0;
+    const double dz = 0.0;
+    HIPCHK(hipMemcpyAsync(e->mt.col + m.slot, &col32, sizeof(int), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(e->mt.rank + m.slot, &rank32, sizeof(int), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(e->mt.iters + m.slot, &one, sizeof(long long), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(e->mt.jk_mode + m.slot, &jm, sizeof(int), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(e->mt.jk_fiber + m.slot, &jf, sizeof(int), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(e->mt.err + m.slot, &dz, sizeof(double), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(e->mt.fit + m.slot, &dz, sizeof(double), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(e->mt.old_fit + m.slot, &dz, sizeof(double), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(e->mt.ls_iter + m.slot, &zero, sizeof(int), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(e->mt.ls_updated_last + m.slot, &zero, sizeof(int), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(e->mt.flags + m.slot, &zero, sizeof(int), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));  // stack temporaries above
+    if (m.jk_mode >= 0) e->flag_jk = true;
+    e->registry.push_back(ticket);
+    e->queue.pop_front();
+    e->n_ktensors++;
+    e->comp_sum += m.rank;
+    new_slots.push_back(m.slot);
+    count++;
+    adjust_edges(e);
+  }
+  if (!new_slots.empty()) {
+    e->slots_dirty = true;
+    // Gramians of the new models, all modes (multi_ktensor.cpp:88-94)
+    int *d_new = nullptr;
+    HIPCHK(hipMalloc((void **)&d_new, new_slots.size() * sizeof(int)));
+    HIPCHK(hipMemcpyAsync(d_new, new_slots.data(), new_slots.size() * sizeof(int),
+                          hipMemcpyHostToDevice, e->stream));
+    GramInitArgs g{};
+    g.slots = d_new;
+    g.n_slots = (int)new_slots.size();
+    g.mt = e->mt;
+    for (int n = 0; n < e->n_modes; n++) {
+      g.factor[n] = e->factor[n];
+      g.I[n] = (int)e->modes[n];
+      g.gram[n] = e->gram[n];
+    }
+    g.n_modes = e->n_modes;
+    HIPCHK(gram_init_launch(g, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipFree(d_new));
+  }
+  if (n_admitted) *n_admitted = count;
+  return CALS_HIP_OK;
+}
+
+// eviction list (src/cals.cpp:336-354) from the fetched status, then remove + compress (:357-362)
+int evict(cals_hip_engine *e, int64_t *n_evicted) {
+  std::vector<int64_t> rm;
+  if (!e->prm.always_evict_first) {
+    for (auto t : e->registry)
+      if (e->h_flags[e->models[t].slot] & 4) rm.push_back(t);
+  } else if (!e->registry.empty()) {
+    const int64_t id = e->occ[0];  // get_leftmost_id, include/multi_ktensor.h:95-100
+    for (auto t : e->registry)
+      if (e->models[t].id == id && id > 0) rm.push_back(t);
+  }
+  for (auto t : rm) {
+    int rc = remove_model(e, t);
+    if (rc) return rc;
+  }
+  if (n_evicted) *n_evicted = (int64_t)rm.size();
+  return compress(e);
+}
+
+}  // namespace
+
+// =============================================================================================
+// C ABI
+// =============================================================================================
+extern "C" {
+
+void cals_hip_default_params(cals_hip_params *p) {
+  p->max_iterations = 200;
+  p->tol = 1e-7;
+  p->line_search = 0;
+  p->line_search_interval = 5;
+  p->line_search_step = 0.0;
+  p->line_search_method = 0;
+  p->force_max_iter = 0;
+  p->always_evict_first = 0;
+}
+
+int cals_hip_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int cals_hip_create(cals_hip_engine **out, int n_modes, const int64_t *modes, int64_t buffer_size,
+                    int device) {
+  if (!out) return CALS_HIP_ERR_ARG;
+  *out = nullptr;
+  cals_hip_engine *e = new cals_hip_engine();
+  *out = e;  // returned even on failure so the caller can read last_error, then destroy
+  if (n_modes < 3 || n_modes > CALS_HIP_MAX_MODES || !modes || buffer_size < 1)
+    return fail(e, CALS_HIP_ERR_ARG, "need 3 <= n_modes <= 8, modes, buffer_size >= 1");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(e, CALS_HIP_ERR_NO_DEVICE,
+                "no HIP device visible: the CALS engine has no CPU fallback");
+  if (device < 0 || device >= ndev) return fail(e, CALS_HIP_ERR_ARG, "device ordinal out of range");
+  HIPCHK(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, device));
+  if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos)
+    return fail(e, CALS_HIP_ERR_NO_DEVICE,
+                std::string("kernels are built for gfx950 only, device is ") + prop.gcnArchName);
+  e->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  e->device = device;
+  e->n_modes = n_modes;
+  e->buffer = buffer_size;
+  for (int n = 0; n < n_modes; n++) {
+    if (modes[n] < 1 || modes[n] > (1 << 24)) return fail(e, CALS_HIP_ERR_ARG, "bad mode size");
+    e->modes[n] = modes[n];
+  }
+  cals_hip_default_params(&e->prm);
+  HIPCHK(hipStreamCreate(&e->stream));
+
+  // layouts: inner mode a = the remaining mode with the least padding waste
+  size_t part_rows_max = 0, krp_max = 0;
+  for (int n = 0; n < n_modes; n++) {
+    ModeLayout &L = e->lay[n];
+    double best = 1e30;
+    for (int k = 0; k < n_modes; k++) {
+      if (k == n) continue;
+      const double waste = (double)round_up((int)modes[k], 16) / (double)modes[k];
+      if (waste < best - 1e-12) {
+        best = waste;
+        L.a_mode = k;
+      }
+    }
+    L.A = (int)modes[L.a_mode];
+    L.Ap = round_up(L.A, 16);
+    L.Mp = round_up((int)modes[n], 16);
+    L.S = 1;
+    for (int k = 0; k < n_modes; k++)
+      if (k != n && k != L.a_mode) {
+        L.s_modes.push_back(k);
+        L.S *= modes[k];
+      }
+    const int m_tiles = L.Mp / 16;
+    L.m_blocks = (m_tiles + 19) / 20;
+    L.MT = mttkrp_pick_mt((m_tiles + L.m_blocks - 1) / L.m_blocks);
+    if (L.MT == 0) return fail(e, CALS_HIP_ERR_ARG, "internal: no MTTKRP tile for this mode size");
+    L.ldPart = L.m_blocks * 16 * L.MT;
+    part_rows_max = std::max<size_t>(part_rows_max, (size_t)L.ldPart * (size_t)L.m_blocks);
+    if (L.s_modes.size() > 1) krp_max = std::max<size_t>(krp_max, (size_t)L.S * (size_t)buffer_size);
+  }
+  int rc;
+  for (int n = 0; n < n_modes; n++) {
+    if ((rc = dev_alloc(e, &e->factor[n], (size_t)(modes[n] * buffer_size)))) return rc;
+    if ((rc = dev_alloc(e, &e->gram[n], (size_t)(CALS_RMAX * buffer_size)))) return rc;
+  }
+  if ((rc = dev_alloc(e, &e->lambda, (size_t)buffer_size))) return rc;
+  const size_t nb_max = (size_t)((buffer_size + CALS_BN - 1) / CALS_BN);
+  size_t ld_max = 0;
+  for (int n = 0; n < n_modes; n++) ld_max = std::max<size_t>(ld_max, (size_t)e->lay[n].ldPart);
+  e->partial_elems = std::max<size_t>((size_t)e->n_cu, nb_max) * ld_max * CALS_BN;
+  (void)part_rows_max;
+  if ((rc = dev_alloc(e, &e->partial, e->partial_elems))) return rc;
+  if (krp_max) {
+    e->krp_elems = krp_max;
+    if ((rc = dev_alloc(e, &e->krp_ws, krp_max))) return rc;
+  }
+  e->max_slots = (int)std::min<int64_t>(buffer_size, 1 << 20);
+  const size_t ms = (size_t)e->max_slots;
+  if ((rc = dev_alloc(e, &e->mt.col, ms))) return rc;
+  if ((rc = dev_alloc(e, &e->mt.rank, ms))) return rc;
+  if ((rc = dev_alloc(e, &e->mt.iters, ms))) return rc;
+  if ((rc = dev_alloc(e, &e->mt.jk_mode, ms))) return rc;
+  if ((rc = dev_alloc(e, &e->mt.jk_fiber, ms))) return rc;
+  if ((rc = dev_alloc(e, &e->mt.err, ms))) return rc;
+  if ((rc = dev_alloc(e, &e->mt.fit, ms))) return rc;
+  if ((rc = dev_alloc(e, &e->mt.old_fit, ms))) return rc;
+  if ((rc = dev_alloc(e, &e->mt.potrf_info, ms))) return rc;
+  if ((rc = dev_alloc(e, &e->mt.ls_iter, ms))) return rc;
+  if ((rc = dev_alloc(e, &e->mt.ls_updated_last, ms))) return rc;
+  if ((rc = dev_alloc(e, &e->mt.bk_err, ms))) return rc;
+  if ((rc = dev_alloc(e, &e->mt.bk_fit, ms))) return rc;
+  if ((rc = dev_alloc(e, &e->mt.bk_old_fit, ms))) return rc;
+  if ((rc = dev_alloc(e, &e->mt.bk_iters, ms))) return rc;
+  if ((rc = dev_alloc(e, &e->mt.flags, ms))) return rc;
+  if ((rc = dev_alloc(e, &e->d_slots, ms))) return rc;
+  if ((rc = dev_alloc(e, &e->d_jk_norms, (size_t)modes[0]))) return rc;
+  e->h_flags.assign(ms, 0);
+  e->h_iters.assign(ms, 0);
+  e->h_err.assign(ms, 0.0);
+  e->h_fit.assign(ms, 0.0);
+  e->h_old_fit.assign(ms, 0.0);
+  for (int s = e->max_slots - 1; s >= 0; s--) e->free_slots.push_back(s);
+  e->occ.assign((size_t)buffer_size, 0);
+  adjust_edges(e);
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return CALS_HIP_OK;
+}
+
+int cals_hip_destroy(cals_hip_engine *e) {
+  if (!e) return CALS_HIP_OK;
+  if (e->stream) (void)hipStreamSynchronize(e->stream);
+  auto fr = [](void *p) {
+    if (p) (void)hipFree(p);
+  };
+  for (int n = 0; n < CALS_HIP_MAX_MODES; n++) {
+    fr(e->factor[n]);
+    fr(e->prev[n]);
+    fr(e->backup[n]);
+    fr(e->gram[n]);
+    fr(e->lay[n].Xp);
+  }
+  fr(e->lambda);
+  fr(e->prev_lambda);
+  fr(e->backup_lambda);
+  fr(e->partial);
+  fr(e->krp_ws);
+  fr(e->d_jk_norms);
+  fr(e->mt.col);
+  fr(e->mt.rank);
+  fr(e->mt.iters);
+  fr(e->mt.jk_mode);
+  fr(e->mt.jk_fiber);
+  fr(e->mt.err);
+  fr(e->mt.fit);
+  fr(e->mt.old_fit);
+  fr(e->mt.potrf_info);
+  fr(e->mt.ls_iter);
+  fr(e->mt.ls_updated_last);
+  fr(e->mt.bk_err);
+  fr(e->mt.bk_fit);
+  fr(e->mt.bk_old_fit);
+  fr(e->mt.bk_iters);
+  fr(e->mt.flags);
+  fr(e->d_slots);
+  for (auto &p : e->ev_pool) {
+    (void)hipEventDestroy(p.a);
+    (void)hipEventDestroy(p.b);
+  }
+  if (e->stream) (void)hipStreamDestroy(e->stream);
+  delete e;
+  return CALS_HIP_OK;
+}
+
+const char *cals_hip_last_error(const cals_hip_engine *e) { return e ? e->err.c_str() : "null engine"; }
+
+int cals_hip_set_tensor(cals_hip_engine *e, const double *X_host) {
+  if (!e || !X_host) return CALS_HIP_ERR_ARG;
+  if (!e->stream) return fail(e, CALS_HIP_ERR_STATE, "engine not initialised");
+  long long total = 1;
+  for (int n = 0; n < e->n_modes; n++) total *= e->modes[n];
+  double *dX = nullptr;
+  HIPCHK(hipMalloc((void **)&dX, (size_t)total * sizeof(double)));
+  HIPCHK(hipMemcpyAsync(dX, X_host, (size_t)total * sizeof(double), hipMemcpyHostToDevice,
+                        e->stream));
+  int dims[CALS_HIP_MAX_MODES];
+  for (int n = 0; n < e->n_modes; n++) dims[n] = (int)e->modes[n];
+  for (int n = 0; n < e->n_modes; n++) {
+    ModeLayout &L = e->lay[n];
+    if (L.Xp) {
+      HIPCHK(hipFree(L.Xp));
+      L.Xp = nullptr;
+    }
+    const size_t elems = (size_t)L.Mp * (size_t)L.Ap * (size_t)L.S;
+    HIPCHK(hipMalloc((void **)&L.Xp, elems * sizeof(double)));
+    HIPCHK(permute_pad_launch(dX, e->n_modes, dims, n, L.a_mode, L.Mp, L.Ap, L.Xp, L.S, e->stream));
+  }
+  // ||X|| and the jackknife norms from the mode-0 slice sums of squares
+  const long long I = e->modes[0], cols = total / I;
+  const int n_part = 256;
+  double *d_part = nullptr, *d_ss = nullptr;
+  HIPCHK(hipMalloc((void **)&d_part, (size_t)n_part * (size_t)I * sizeof(double)));
+  HIPCHK(hipMalloc((void **)&d_ss, (size_t)I * sizeof(double)));
+  HIPCHK(slice_sumsq_launch(dX, I, cols, d_part, n_part, d_ss, e->stream));
+  std::vector<double> ss((size_t)I);
+  HIPCHK(hipMemcpyAsync(ss.data(), d_ss, (size_t)I * sizeof(double), hipMemcpyDeviceToHost,
+                        e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  double sum0 = 0.0;
+  for (long long i = 0; i < I; i++) sum0 += ss[(size_t)i];
+  e->X_norm = std::sqrt(sum0);
+  e->jk_norms.resize((size_t)I);
+  for (long long i = 0; i < I; i++) e->jk_norms[(size_t)i] = std::sqrt(sum0 - ss[(size_t)i]);
+  HIPCHK(hipMemcpyAsync(e->d_jk_norms, e->jk_norms.data(), (size_t)I * sizeof(double),
+                        hipMemcpyHostToDevice, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  HIPCHK(hipFree(d_part));
+  HIPCHK(hipFree(d_ss));
+  HIPCHK(hipFree(dX));
+  e->has_tensor = true;
+  return CALS_HIP_OK;
+}
+
+int cals_hip_set_params(cals_hip_engine *e, const cals_hip_params *p) {
+  if (!e || !p) return CALS_HIP_ERR_ARG;
+  if (p->max_iterations < 1) return fail(e, CALS_HIP_ERR_ARG, "max_iterations must be >= 1");
+  if (p->line_search && p->line_search_method != 0)
+    return fail(e, CALS_HIP_ERR_ARG,
+                "only ls::NO_ERROR_CHECKING runs on the device path (SURVEY.md section 8a15)");
+  if (p->line_search && p->line_search_interval < 1)
+    return fail(e, CALS_HIP_ERR_ARG, "line_search_interval must be >= 1");
+  e->prm = *p;
+  return CALS_HIP_OK;
+}
+
+int cals_hip_enqueue(cals_hip_engine *e, int64_t rank, double *const *factors, double *lambda,
+                     int jk_mode, int64_t jk_fiber, int64_t *ticket) {
+  if (!e || !factors || !lambda) return CALS_HIP_ERR_ARG;
+  if (rank < 1 || rank > CALS_HIP_MAX_RANK)
+    return fail(e, CALS_HIP_ERR_ARG, "rank must be in [1, CALS_HIP_MAX_RANK]");
+  if (rank > e->buffer)  // the reference would spin forever
+    return fail(e, CALS_HIP_ERR_ARG, "rank exceeds buffer_size");
+  if (jk_mode >= e->n_modes) return fail(e, CALS_HIP_ERR_ARG, "jk_mode out of range");
+  if (jk_mode >= 0 && (jk_fiber < 0 || jk_fiber >= e->modes[jk_mode]))
+    return fail(e, CALS_HIP_ERR_ARG, "jk_fiber out of range");
+  if (jk_mode > 0)
+    return fail(e, CALS_HIP_ERR_ARG, "jackknife norms exist for mode 0 only (utils.cpp:103-152)");
+  HostModel m;
+  m.rank = rank;
+  m.factors.assign(factors, factors + e->n_modes);
+  for (auto p : m.factors)
+    if (!p) return fail(e, CALS_HIP_ERR_ARG, "null factor pointer");
+  m.lambda = lambda;
+  m.jk_mode = jk_mode < 0 ? -1 : jk_mode;
+  m.jk_fiber = jk_fiber;
+  e->models.push_back(m);
+  const int64_t t = (int64_t)e->models.size() - 1;
+  e->queue.push_back(t);
+  if (ticket) *ticket = t;
+  return CALS_HIP_OK;
+}
+
+int cals_hip_admit(cals_hip_engine *e, int64_t *n_admitted) {
+  if (!e) return CALS_HIP_ERR_ARG;
+  if (!e->has_tensor) return fail(e, CALS_HIP_ERR_STATE, "set_tensor first");
+  return admit(e, n_admitted);
+}
+
+int cals_hip_sweep(cals_hip_engine *e, int64_t n_sweeps) {
+  if (!e) return CALS_HIP_ERR_ARG;
+  if (!e->has_tensor) return fail(e, CALS_HIP_ERR_STATE, "set_tensor first");
+  for (int64_t s = 0; s < n_sweeps; s++) {
+    int rc = sweep_once(e, false);
+    if (rc) return rc;
+  }
+  return CALS_HIP_OK;
+}
+
+int cals_hip_evict(cals_hip_engine *e, int64_t *n_evicted) {
+  if (!e) return CALS_HIP_ERR_ARG;
+  int rc = fetch_status(e);
+  if (rc) return rc;
+  return evict(e, n_evicted);
+}
+
+int cals_hip_run(cals_hip_engine *e, cals_hip_report *rep) {
+  if (!e) return CALS_HIP_ERR_ARG;
+  if (!e->has_tensor) return fail(e, CALS_HIP_ERR_STATE, "set_tensor first");
+  const double t0 = now_ms();
+  e->n_ktensors = e->comp_sum = e->ls_performed = e->ls_failed = 0;
+  int64_t iter = 0;
+  HIPCHK(hipStreamSynchronize(e->stream));
+  const double t_loop = now_ms();
+  bool converged = e->queue.empty() && e->registry.empty();
+  while (!converged) {
+    iter++;
+    int rc = admit(e, nullptr);
+    if (rc) return rc;
+    if ((rc = sweep_once(e, true))) return rc;
+    if ((rc = fetch_status(e))) return rc;
+    if (e->prm.line_search)
+      for (auto t : e->registry) {
+        const int f = e->h_flags[e->models[t].slot];
+        if (f & 1) e->ls_performed++;
+        if (f & 2) e->ls_failed++;
+      }
+    if ((rc = evict(e, nullptr))) return rc;
+    converged = e->queue.empty() && e->registry.empty();
+  }
+  HIPCHK(hipStreamSynchronize(e->stream));
+  const double t1 = now_ms();
+  if (rep) {
+    rep->iter = iter;
+    rep->n_ktensors = e->n_ktensors;
+    rep->ktensor_comp_sum = e->comp_sum;
+    rep->ls_performed = e->ls_performed;
+    rep->ls_failed = e->ls_failed;
+    rep->X_norm = e->X_norm;
+    rep->total_ms = t1 - t0;
+    rep->loop_ms = t1 - t_loop;
+  }
+  return CALS_HIP_OK;
+}
+
+int cals_hip_model_result(const cals_hip_engine *e, int64_t ticket, cals_hip_model_status *st) {
+  if (!e || !st || ticket < 0 || ticket >= (int64_t)e->models.size()) return CALS_HIP_ERR_ARG;
+  *st = e->models[(size_t)ticket].st;
+  return CALS_HIP_OK;
+}
+
+int64_t cals_hip_active_cols(const cals_hip_engine *e) { return e ? (e->registry.empty() ? 0 : e->end) : 0; }
+int64_t cals_hip_models_in_flight(const cals_hip_engine *e) { return e ? (int64_t)e->registry.size() : 0; }
+int64_t cals_hip_queue_size(const cals_hip_engine *e) { return e ? (int64_t)e->queue.size() : 0; }
+
+int cals_hip_synchronize(cals_hip_engine *e) {
+  if (!e) return CALS_HIP_ERR_ARG;
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return CALS_HIP_OK;
+}
+
+int cals_hip_debug_mttkrp(cals_hip_engine *e, int mode, double *G_host) {
+  if (!e || !G_host || mode < 0 || mode >= e->n_modes) return CALS_HIP_ERR_ARG;
+  if (!e->has_tensor) return fail(e, CALS_HIP_ERR_STATE, "set_tensor first");
+  if (e->registry.empty()) return fail(e, CALS_HIP_ERR_STATE, "no model in flight");
+  const int64_t R = e->end;
+  Geo g;
+  int rc = launch_mttkrp(e, mode, R, &g);
+  if (rc) return rc;
+  const ModeLayout &L = e->lay[mode];
+  const size_t tile = (size_t)L.ldPart * CALS_BN;
+  std::vector<double> part((size_t)g.NB * g.T * tile);
+  HIPCHK(hipMemcpyAsync(part.data(), e->partial, part.size() * sizeof(double),
+                        hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  const int64_t I = e->modes[mode];
+  for (int64_t c = 0; c < R; c++)
+    for (int64_t i = 0; i < I; i++) {
+      double s = 0.0;
+      const double *p = part.data() + (size_t)(c >> 7) * g.T * tile + i + (size_t)L.ldPart * (c & 127);
+      for (int t = 0; t < g.T; t++) s += p[(size_t)t * tile];
+      G_host[i + I * c] = s;
+    }
+  return CALS_HIP_OK;
+}
+
+int cals_hip_debug_get_factor(cals_hip_engine *e, int mode, double *host) {
+  if (!e || !host || mode < 0 || mode >= e->n_modes) return CALS_HIP_ERR_ARG;
+  HIPCHK(hipMemcpyAsync(host, e->factor[mode], sizeof(double) * (size_t)(e->modes[mode] * e->end),
+                        hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return CALS_HIP_OK;
+}
+
+int cals_hip_debug_get_lambda(cals_hip_engine *e, double *host) {
+  if (!e || !host) return CALS_HIP_ERR_ARG;
+  HIPCHK(hipMemcpyAsync(host, e->lambda, sizeof(double) * (size_t)e->end, hipMemcpyDeviceToHost,
+                        e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return CALS_HIP_OK;
+}
+
+int cals_hip_debug_get_gramian(cals_hip_engine *e, int mode, double *host) {
+  if (!e || !host || mode < 0 || mode >= e->n_modes) return CALS_HIP_ERR_ARG;
+  HIPCHK(hipMemcpyAsync(host, e->gram[mode], sizeof(double) * (size_t)(CALS_RMAX * e->end),
+                        hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return CALS_HIP_OK;
+}
+
+int cals_hip_debug_model_status(cals_hip_engine *e, int64_t ticket, cals_hip_model_status *st,
+                                int64_t *col) {
+  if (!e || !st || ticket < 0 || ticket >= (int64_t)e->models.size()) return CALS_HIP_ERR_ARG;
+  const HostModel &m = e->models[(size_t)ticket];
+  if (m.state != 1) {
+    *st = m.st;
+    if (col) *col = -1;
+    return CALS_HIP_OK;
+  }
+  int rc = fetch_status(e);
+  if (rc) return rc;
+  st->iters = e->h_iters[m.slot];
+  st->approx_error = e->h_err[m.slot];
+  st->fit = e->h_fit[m.slot];
+  st->old_fit = e->h_old_fit[m.slot];
+  st->evicted = 0;
+  if (col) *col = m.col;
+  return CALS_HIP_OK;
+}
+
+int cals_hip_debug_get_norms(cals_hip_engine *e, double *X_norm, double *jk_norms) {
+  if (!e) return CALS_HIP_ERR_ARG;
+  if (!e->has_tensor) return fail(e, CALS_HIP_ERR_STATE, "set_tensor first");
+  if (X_norm) *X_norm = e->X_norm;
+  if (jk_norms) std::memcpy(jk_norms, e->jk_norms.data(), e->jk_norms.size() * sizeof(double));
+  return CALS_HIP_OK;
+}
+
+int cals_hip_set_profiling(cals_hip_engine *e, int enabled) {
+  if (!e) return CALS_HIP_ERR_ARG;
+  if (!enabled) prof_collect(e);
+  e->profiling = enabled != 0;
+  return CALS_HIP_OK;
+}
+
+int cals_hip_get_kernel_stats(cals_hip_engine *e, cals_hip_kernel_stats *out) {
+  if (!e || !out) return CALS_HIP_ERR_ARG;
+  prof_collect(e);
+  *out = e->stats;
+  return CALS_HIP_OK;
+}
+
+int cals_hip_reset_kernel_stats(cals_hip_engine *e) {
+  if (!e) return CALS_HIP_ERR_ARG;
+  prof_collect(e);
+  e->stats = cals_hip_kernel_stats{};
+  return CALS_HIP_OK;
+}
+
+void *cals_hip_stream(cals_hip_engine *e) { return e ? (void *)e->stream : nullptr; }
+
+}  // extern "C"

@@ -1,0 +1,136 @@
+// Internal declarations shared by the HIP kernels and the engine (not part of the C ABI).
+#ifndef CALS_HIP_INTERNAL_H
+#define CALS_HIP_INTERNAL_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define CALS_MAX_MODES 8
+#define CALS_RMAX 32          // rank limit of the batched per-model kernels; Gramian store ld
+#define CALS_BN 128           // columns of the multi-factor per MTTKRP workgroup (4 waves x 32)
+
+namespace calship {
+
+// ---------------------------------------------------------------------------------------------
+// MTTKRP  G[m,c] = sum_{a,s} Xp[m,a,s] * P[a,c] * Q[s,c]     (DESIGN.md "MTTKRP kernel")
+// ---------------------------------------------------------------------------------------------
+struct MttkrpArgs {
+  const double *Xp;  // permuted, zero-padded tensor copy for this mode: [Mp][Ap][S], m fastest
+  const double *P;   // factor of the inner ("a") mode, A x R, ld = ldP
+  const double *Q;   // factor (or Khatri-Rao of the factors) of the streamed modes, S x R, ld = ldQ
+  double *partial;   // split partial results: [NB*T] tiles of ldPart x CALS_BN, col-major
+  long long S, ldP, ldQ;
+  int Mp, Ap, A;
+  int R;             // active columns
+  int NB, T;         // column blocks, team size (workgroups per column block)
+  int ldPart;        // rows of one partial tile (= m_blocks * 16 * MT)
+  int grid;          // NB * T
+};
+
+// smallest supported tile count >= mt (0 if mt > max): instantiated MT values
+int mttkrp_pick_mt(int m_tiles);
+size_t mttkrp_lds_bytes(int MT);
+hipError_t mttkrp_launch(int MT, int m_blocks, const MttkrpArgs &a, hipStream_t st);
+
+// Q[s,c] for N > 3: Khatri-Rao of the streamed modes' factors (first streamed mode fastest)
+struct KrpArgs {
+  const double *F[CALS_MAX_MODES];
+  long long ld[CALS_MAX_MODES];
+  int dims[CALS_MAX_MODES];
+  int n;         // number of streamed modes
+  long long S;   // prod(dims)
+  int R;
+  double *Q;     // S x R, ld = S
+};
+hipError_t krp_launch(const KrpArgs &a, hipStream_t st);
+
+// ---------------------------------------------------------------------------------------------
+// per-model state (device arrays indexed by slot)
+// ---------------------------------------------------------------------------------------------
+struct ModelTable {
+  int *col;            // first column in every multi-factor
+  int *rank;
+  long long *iters;    // Ktensor::iters
+  int *jk_mode;        // -1: regular model
+  int *jk_fiber;
+  double *err, *fit, *old_fit;
+  int *potrf_info;     // last dpotrf info (0 ok)
+  // line search (ls::LineSearchParams, include/utils/line_search.h:15-32)
+  int *ls_iter;
+  int *ls_updated_last;
+  double *bk_err, *bk_fit, *bk_old_fit;  // backup_ktensor scalars
+  long long *bk_iters;
+  int *flags;          // bit0: extrapolated this sweep, bit1: reversed this sweep, bit2: evict
+};
+
+struct UpdateArgs {
+  const int *slots;    // active slots, one wave each
+  int n_slots;
+  ModelTable mt;
+  double *factor;      // multi-factor of this mode, I x buffer, ld = I
+  int I;
+  const double *partial;  // MTTKRP partial tiles
+  int NB, T, ldPart;
+  double *gram[CALS_MAX_MODES];  // column-indexed Gramian stores: CALS_RMAX x buffer, ld CALS_RMAX
+  double *lambda;      // per column
+  int n_modes, mode;
+  int is_last;
+  double X_norm;
+  const double *jk_norms;
+};
+hipError_t update_launch(const UpdateArgs &a, int rmax_needed, hipStream_t st);
+
+// Gramians of all modes for freshly admitted models (MultiKtensor::add, multi_ktensor.cpp:88-94)
+struct GramInitArgs {
+  const int *slots;
+  int n_slots;
+  ModelTable mt;
+  const double *factor[CALS_MAX_MODES];
+  int I[CALS_MAX_MODES];
+  double *gram[CALS_MAX_MODES];
+  int n_modes;
+};
+hipError_t gram_init_launch(const GramInitArgs &a, hipStream_t st);
+
+// line search + end-of-sweep bookkeeping
+struct LsArgs {
+  const int *slots;
+  int n_slots;
+  ModelTable mt;
+  double *factor[CALS_MAX_MODES];
+  double *prev[CALS_MAX_MODES];
+  double *backup[CALS_MAX_MODES];
+  int I[CALS_MAX_MODES];
+  double *gram[CALS_MAX_MODES];
+  double *lambda, *prev_lambda, *backup_lambda;
+  int n_modes;
+  int interval;
+  double step;            // 0 => cbrt(iters)
+  long long max_iter;
+};
+hipError_t ls_snapshot_launch(const LsArgs &a, hipStream_t st);  // cals.cpp:203-211
+hipError_t ls_launch(const LsArgs &a, hipStream_t st);           // cals.cpp:310-331
+
+struct FinishArgs {
+  const int *slots;
+  int n_slots;
+  ModelTable mt;
+  long long max_iter;
+  double tol;
+  int force_max_iter;
+  int evict_enabled;  // 0: cals_hip_sweep (iters++ for everybody)
+};
+hipError_t finish_launch(const FinishArgs &a, hipStream_t st);   // cals.cpp:336-354
+
+// set-up kernels
+hipError_t permute_pad_launch(const double *X, int n_modes, const int *dims, int m_mode,
+                              int a_mode, int Mp, int Ap, double *Xp, long long S,
+                              hipStream_t st);
+hipError_t slice_sumsq_launch(const double *X, long long I, long long cols, double *partial,
+                              int n_part, double *ss_out, hipStream_t st);
+// move `ncols` columns of an (rows x *) col-major buffer left by `off` columns (compress)
+hipError_t move_columns_launch(double *buf, long long rows, long long src_col, long long ncols,
+                               long long off, hipStream_t st);
+
+}  // namespace calship
+#endif

@@ -1,0 +1,568 @@
+// Batched per-model kernels of the CALS sweep on gfx950: one wavefront per in-flight model.
+//
+//   update_kernel   src/cals.cpp:239-256 for one mode, all models at once:
+//                   sum of the MTTKRP split partials (fixed order) -> hadamard_but_one
+//                   (src/utils/utils.cpp:161-172) -> dpotrf('L') + 2x dtrsm
+//                   (src/utils/update.cpp:178-192) -> set_jk_fiber(0) (include/ktensor.h:316-325)
+//                   -> Ktensor::normalize(mode, iter) (src/ktensor.cpp:66-83) -> update_gramian
+//                   (src/utils/utils.cpp:174-178, on v_mfma_f64_16x16x4_f64); on the last mode also
+//                   hadamard_all + compute_fast_error + calculate_new_fit (src/cals.cpp:281-303,
+//                   src/utils/error.cpp:64-89, include/ktensor.h:178-183) while G is still in
+//                   registers (G_last of src/cals.cpp:230-234 is never materialised).
+//   ls_*            line search, NO_ERROR_CHECKING (src/utils/line_search.cpp:24-71, 228-271)
+//   finish_kernel   eviction rule + iters++ (src/cals.cpp:336-354)
+//
+// Everything a model owns is indexed by its first column `col` in the multi-factor buffers:
+// factor columns [col, col+r), lambda[col..], and an r x r Gramian per mode stored in columns
+// [col, col+r) of a CALS_RMAX x buffer matrix (ld = CALS_RMAX).
+#include "cals_hip_internal.h"
+
+#include <cfloat>
+
+namespace calship {
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+
+// Gamma = P^T P for the I x r panel (ld) with r <= 32, on the f64 matrix cores: each k-step covers 4
+// rows; lane (lcol, krow) supplies P[i0+krow, lcol] as both the A and the B operand.
+// Written to g (ld = CALS_RMAX).  Must be called by a whole wave with EXEC all ones.
+__device__ __forceinline__ void gramian_wave(const double *panel, int rows, long long ld, int r,
+                                             double *g, int lane) {
+  const int krow = lane >> 4, lcol = lane & 15;
+  const bool two = r > 16;
+  v4d a00 = {0.0, 0.0, 0.0, 0.0}, a01 = {0.0, 0.0, 0.0, 0.0}, a11 = {0.0, 0.0, 0.0, 0.0};
+  const bool c0ok = lcol < r, c1ok = (16 + lcol) < r;
+  for (int i0 = 0; i0 < rows; i0 += 4) {
+    const int i = i0 + krow;
+    const bool rok = i < rows;
+    const double p0 = (rok && c0ok) ? panel[i + ld * lcol] : 0.0;
+    a00 = __builtin_amdgcn_mfma_f64_16x16x4f64(p0, p0, a00, 0, 0, 0);
+    if (two) {
+      const double p1 = (rok && c1ok) ? panel[i + ld * (16 + lcol)] : 0.0;
+      a01 = __builtin_amdgcn_mfma_f64_16x16x4f64(p0, p1, a01, 0, 0, 0);
+      a11 = __builtin_amdgcn_mfma_f64_16x16x4f64(p1, p1, a11, 0, 0, 0);
+    }
+  }
+  // f64 C/D layout: lane holds D[row = krow + 4*reg][col = lcol]
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg) {
+    const int row = krow + 4 * reg;
+    if (row < r && lcol < r) g[row + CALS_RMAX * lcol] = a00[reg];
+    if (two) {
+      if (row < r && 16 + lcol < r) {
+        g[row + CALS_RMAX * (16 + lcol)] = a01[reg];
+        g[(16 + lcol) + CALS_RMAX * row] = a01[reg];
+      }
+      if (16 + row < r && 16 + lcol < r) g[(16 + row) + CALS_RMAX * (16 + lcol)] = a11[reg];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// update
+// ---------------------------------------------------------------------------------------------
+template <int RMAX>
+__device__ __forceinline__ void update_body(const UpdateArgs &a, int slot, int r, double *Hs,
+                                            double *dinv, double *lams) {
+  const int lane = threadIdx.x;
+  const int col = a.mt.col[slot];
+  const long long iters = a.mt.iters[slot];
+  const int jkf = (a.mt.jk_mode[slot] == a.mode) ? a.mt.jk_fiber[slot] : -1;
+  const int I = a.I;
+
+  // H = hadamard of the other modes' Gramians (hadamard_but_one)
+  for (int e = lane; e < r * r; e += 64) {
+    const int i = e % r, j = e / r;
+    double h = 1.0;
+    for (int m = 0; m < a.n_modes; ++m)
+      if (m != a.mode) h *= a.gram[m][i + CALS_RMAX * (long long)(col + j)];
+    Hs[i + RMAX * j] = h;
+  }
+  __syncthreads();
+
+  // dpotrf('L') restated as unblocked dpotf2 (lane = row).  info != 0: stop, keep going with
+  // whatever is in H, as the reference does (update.cpp:183-185 only logs).
+  int info = 0;
+  for (int j = 0; j < r; ++j) {
+    double ajj = Hs[j + RMAX * j];
+    for (int k = 0; k < j; ++k) ajj -= Hs[j + RMAX * k] * Hs[j + RMAX * k];
+    if (!(ajj > 0.0)) {
+      __syncthreads();
+      if (lane == 0) Hs[j + RMAX * j] = ajj;
+      info = j + 1;
+      break;
+    }
+    ajj = sqrt(ajj);
+    double s = 0.0;
+    if (lane > j && lane < r) {
+      s = Hs[lane + RMAX * j];
+      for (int k = 0; k < j; ++k) s -= Hs[lane + RMAX * k] * Hs[j + RMAX * k];
+      s = s / ajj;
+    }
+    __syncthreads();
+    if (lane == j)
+      Hs[j + RMAX * j] = ajj;
+    else if (lane > j && lane < r)
+      Hs[lane + RMAX * j] = s;
+    __syncthreads();
+  }
+  __syncthreads();
+  if (lane < r) dinv[lane] = 1.0 / Hs[lane + RMAX * lane];
+  if (lane == 0) a.mt.potrf_info[slot] = info;
+  __syncthreads();
+
+  double *fac = a.factor + (long long)I * col;
+  const long long tile = (long long)a.ldPart * CALS_BN;
+  const bool first = (iters == 1);
+
+  double t3 = 0.0;
+
+  // pass 1, one row per lane: G row -> two triangular solves -> unnormalised factor row
+  for (int i = lane; i < I; i += 64) {
+    double x[RMAX], g[RMAX];
+    // L stays in LDS (broadcast reads): without this barrier LICM hoists all r^2/2 entries of L
+    // out of the row loop into VGPRs and the kernel spills.
+    asm volatile("" ::: "memory");
+    // G row = sum over the T team partials, fixed order
+#pragma unroll
+    for (int c = 0; c < RMAX; ++c) {
+      x[c] = 0.0;
+      if (c < r) {
+        const int cg = col + c;
+        const double *p = a.partial + (long long)(cg >> 7) * a.T * tile + i +
+                          (long long)a.ldPart * (cg & (CALS_BN - 1));
+        double s = 0.0;
+        for (int t = 0; t < a.T; ++t) s += p[t * tile];
+        x[c] = s;
+      }
+      g[c] = x[c];
+    }
+    // B := B * inv(L^T)   (dtrsm Right, Lower, Trans)
+#pragma unroll
+    for (int k = 0; k < RMAX; ++k) {
+      if (k < r) {
+        x[k] = dinv[k] * x[k];
+#pragma unroll
+        for (int j = k + 1; j < RMAX; ++j)
+          if (j < r) x[j] -= Hs[j + RMAX * k] * x[k];
+      }
+    }
+    // B := B * inv(L)     (dtrsm Right, Lower, NoTrans)
+#pragma unroll
+    for (int j = RMAX - 1; j >= 0; --j) {
+      if (j < r) {
+#pragma unroll
+        for (int k = j + 1; k < RMAX; ++k)
+          if (k < r) x[j] -= Hs[k + RMAX * j] * x[k];
+        x[j] = dinv[j] * x[j];
+      }
+    }
+    if (i == jkf) {
+#pragma unroll
+      for (int c = 0; c < RMAX; ++c) x[c] *= 0.0;
+    }
+#pragma unroll
+    for (int c = 0; c < RMAX; ++c) {
+      if (c < r) {
+        fac[i + (long long)I * c] = x[c];
+        t3 += x[c] * g[c];  // = lambda_c * A[i,c] * G[i,c] of compute_fast_error's term3
+      }
+    }
+  }
+  t3 = wave_sum(t3);
+  __syncthreads();
+
+  // pass 2, one column at a time: scale = 2-norm on a model's first sweep, signed max-abs entry
+  // (cblas_idamax: first index of the largest |x|) afterwards; cblas_dscal by 1/lambda unless 0
+  for (int c = 0; c < r; ++c) {
+    double *fc = fac + (long long)I * c;
+    double lam;
+    if (first) {
+      double ss = 0.0;
+      for (int i = lane; i < I; i += 64) ss += fc[i] * fc[i];
+      lam = sqrt(wave_sum(ss));
+    } else {
+      double m = -1.0, v = 0.0;
+      int ix = 0x7fffffff;
+      for (int i = lane; i < I; i += 64) {
+        const double xv = fc[i], ax = fabs(xv);
+        if (ax > m) {
+          m = ax;
+          v = xv;
+          ix = i;
+        }
+      }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        const double m2 = __shfl_xor(m, off);
+        const double v2 = __shfl_xor(v, off);
+        const int i2 = __shfl_xor(ix, off);
+        const bool take = (m2 > m) || (m2 == m && i2 < ix);
+        m = take ? m2 : m;
+        v = take ? v2 : v;
+        ix = take ? i2 : ix;
+      }
+      lam = v;
+    }
+    if (lane == 0) {
+      lams[c] = lam;
+      a.lambda[col + c] = lam;
+    }
+    if (lam != 0.0) {
+      const double sc = 1.0 / lam;
+      for (int i = lane; i < I; i += 64) fc[i] = sc * fc[i];
+    }
+  }
+  __syncthreads();
+
+  gramian_wave(fac, I, I, r, a.gram[a.mode] + CALS_RMAX * (long long)col, lane);
+
+  if (a.is_last) {
+    __syncthreads();
+    double t2 = 0.0;
+    for (int e = lane; e < r * r; e += 64) {
+      const int i = e % r, j = e / r;
+      double h = 1.0;
+      for (int m = 0; m < a.n_modes; ++m) h *= a.gram[m][i + CALS_RMAX * (long long)(col + j)];
+      t2 += lams[i] * lams[j] * h;
+    }
+    t2 = wave_sum(t2);
+    if (lane == 0) {
+      const int jm = a.mt.jk_mode[slot];
+      const double xn = (jm >= 0) ? a.jk_norms[a.mt.jk_fiber[slot]] : a.X_norm;
+      const double e2 = fmax(xn * xn + t2 - 2.0 * t3, 0.0);
+      const double err = sqrt(e2);
+      a.mt.err[slot] = err;
+      const double of = a.mt.fit[slot];
+      a.mt.old_fit[slot] = of;
+      a.mt.fit[slot] = 1.0 - fabs(err) / a.X_norm;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(64) update_kernel(const UpdateArgs a) {
+  __shared__ double Hs[CALS_RMAX * CALS_RMAX];
+  __shared__ double dinv[CALS_RMAX];
+  __shared__ double lams[CALS_RMAX];
+  const int slot = a.slots[blockIdx.x];
+  const int r = a.mt.rank[slot];
+  if (r <= 4)
+    update_body<4>(a, slot, r, Hs, dinv, lams);
+  else if (r <= 8)
+    update_body<8>(a, slot, r, Hs, dinv, lams);
+  else if (r <= 12)
+    update_body<12>(a, slot, r, Hs, dinv, lams);
+  else if (r <= 16)
+    update_body<16>(a, slot, r, Hs, dinv, lams);
+  else if (r <= 20)
+    update_body<20>(a, slot, r, Hs, dinv, lams);
+  else if (r <= 24)
+    update_body<24>(a, slot, r, Hs, dinv, lams);
+  else
+    update_body<32>(a, slot, r, Hs, dinv, lams);
+}
+
+hipError_t update_launch(const UpdateArgs &a, int, hipStream_t st) {
+  if (a.n_slots <= 0) return hipSuccess;
+  hipLaunchKernelGGL(update_kernel, dim3(a.n_slots), dim3(64), 0, st, a);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Gramians at admission (MultiKtensor::add, src/multi_ktensor.cpp:88-94)
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) gram_init_kernel(const GramInitArgs a) {
+  const int slot = a.slots[blockIdx.x];
+  const int m = blockIdx.y;
+  const int col = a.mt.col[slot];
+  const int r = a.mt.rank[slot];
+  gramian_wave(a.factor[m] + (long long)a.I[m] * col, a.I[m], a.I[m], r,
+               a.gram[m] + CALS_RMAX * (long long)col, threadIdx.x);
+}
+
+hipError_t gram_init_launch(const GramInitArgs &a, hipStream_t st) {
+  if (a.n_slots <= 0) return hipSuccess;
+  hipLaunchKernelGGL(gram_init_kernel, dim3(a.n_slots, a.n_modes), dim3(64), 0, st, a);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// line search (NO_ERROR_CHECKING)
+// ---------------------------------------------------------------------------------------------
+// prev_ktensor.copy(ktensor) when ls.iter == interval-1 (src/cals.cpp:203-211)
+__global__ void __launch_bounds__(256) ls_snapshot_kernel(const LsArgs a) {
+  const int slot = a.slots[blockIdx.x];
+  if (a.mt.ls_iter[slot] != a.interval - 1) return;
+  const int col = a.mt.col[slot], r = a.mt.rank[slot];
+  for (int m = 0; m < a.n_modes; ++m) {
+    const long long n = (long long)a.I[m] * r, off = (long long)a.I[m] * col;
+    for (long long e = threadIdx.x; e < n; e += 256) a.prev[m][off + e] = a.factor[m][off + e];
+  }
+  if (threadIdx.x < r) a.prev_lambda[col + threadIdx.x] = a.lambda[col + threadIdx.x];
+}
+
+// ls::line_search (src/utils/line_search.cpp:228-271) for every model, after the error update.
+__global__ void __launch_bounds__(256) ls_kernel(const LsArgs a) {
+  const int slot = a.slots[blockIdx.x];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int col = a.mt.col[slot], r = a.mt.rank[slot];
+  const long long iters = a.mt.iters[slot];
+  __shared__ double s_lam[CALS_RMAX];
+  if (tid == 0) a.mt.flags[slot] = 0;
+  // "Make sure extrapolation doesn't happen right before a Ktensor is evicted" (cals.cpp:314-316)
+  if (iters >= a.max_iter) return;
+  int ls_iter = a.mt.ls_iter[slot] + 1;
+  int flags = 0;
+  const double step = (a.step == 0.0) ? cbrt((double)iters) : a.step;
+  bool regram = false;
+  if (a.mt.ls_updated_last[slot]) {
+    if (a.mt.bk_err[slot] < a.mt.err[slot]) {
+      // revert to the backup (Ktensor::copy, src/ktensor.cpp:163-181: scalars, lambda, factors)
+      flags |= 2;
+      ls_iter = 0;
+      for (int m = 0; m < a.n_modes; ++m) {
+        const long long n = (long long)a.I[m] * r, off = (long long)a.I[m] * col;
+        for (long long e = tid; e < n; e += 256) a.factor[m][off + e] = a.backup[m][off + e];
+      }
+      if (tid < r) a.lambda[col + tid] = a.backup_lambda[col + tid];
+      regram = true;
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    if (a.mt.ls_updated_last[slot]) {
+      a.mt.ls_updated_last[slot] = 0;
+      if (flags & 2) {
+        a.mt.err[slot] = a.mt.bk_err[slot];
+        a.mt.fit[slot] = a.mt.bk_fit[slot];
+        a.mt.old_fit[slot] = a.mt.bk_old_fit[slot];
+        a.mt.iters[slot] = a.mt.bk_iters[slot];
+      }
+    }
+  }
+  __syncthreads();
+  if (ls_iter == a.interval) {
+    flags |= 1;
+    ls_iter = 0;
+    // backup_ktensor.copy(ktensor)
+    for (int m = 0; m < a.n_modes; ++m) {
+      const long long n = (long long)a.I[m] * r, off = (long long)a.I[m] * col;
+      for (long long e = tid; e < n; e += 256) a.backup[m][off + e] = a.factor[m][off + e];
+    }
+    if (tid < r) a.backup_lambda[col + tid] = a.lambda[col + tid];
+    if (tid == 0) {
+      a.mt.bk_err[slot] = a.mt.err[slot];
+      a.mt.bk_fit[slot] = a.mt.fit[slot];
+      a.mt.bk_old_fit[slot] = a.mt.old_fit[slot];
+      a.mt.bk_iters[slot] = a.mt.iters[slot];
+      a.mt.ls_updated_last[slot] = 1;
+    }
+    __syncthreads();
+    // line_search_no_error_checking (line_search.cpp:24-71): denormalize both (factor 0 *= lambda),
+    // A += step*(A - A_prev) on every mode, normalize() (2-norm per column, lambda = product).
+    for (int c = wave; c < r; c += 4) {
+      const double lc = a.lambda[col + c], lp = a.prev_lambda[col + c];
+      double lam = 1.0;
+      for (int m = 0; m < a.n_modes; ++m) {
+        double *f = a.factor[m] + (long long)a.I[m] * (col + c);
+        const double *pf = a.prev[m] + (long long)a.I[m] * (col + c);
+        double ss = 0.0;
+        for (int i = lane; i < a.I[m]; i += 64) {
+          double x = f[i], p = pf[i];
+          if (m == 0) {
+            x *= lc;
+            p *= lp;
+          }
+          x += step * (x - p);
+          f[i] = x;
+          ss += x * x;
+        }
+        const double coeff = sqrt(wave_sum(ss));
+        const double s = 1.0 / coeff;
+        for (int i = lane; i < a.I[m]; i += 64) f[i] = s * f[i];
+        lam *= coeff;
+      }
+      if (lane == 0) a.lambda[col + c] = lam;
+    }
+    if (tid == 0) {
+      a.mt.err[slot] = DBL_MAX;
+      const double of = a.mt.fit[slot];
+      a.mt.old_fit[slot] = of;
+      a.mt.fit[slot] = 1.0 - fabs(DBL_MAX) / 1.0;
+    }
+    regram = true;
+  }
+  __syncthreads();
+  if (regram) {  // update_gramians
+    for (int m = wave; m < a.n_modes; m += 4)
+      gramian_wave(a.factor[m] + (long long)a.I[m] * col, a.I[m], a.I[m], r,
+                   a.gram[m] + CALS_RMAX * (long long)col, lane);
+  }
+  if (tid == 0) {
+    a.mt.ls_iter[slot] = ls_iter;
+    a.mt.flags[slot] = flags;
+  }
+  (void)s_lam;
+}
+
+hipError_t ls_snapshot_launch(const LsArgs &a, hipStream_t st) {
+  if (a.n_slots <= 0) return hipSuccess;
+  hipLaunchKernelGGL(ls_snapshot_kernel, dim3(a.n_slots), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+
+hipError_t ls_launch(const LsArgs &a, hipStream_t st) {
+  if (a.n_slots <= 0) return hipSuccess;
+  hipLaunchKernelGGL(ls_kernel, dim3(a.n_slots), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// end of sweep: eviction rule + iters++ (src/cals.cpp:336-354, always_evict_first is host-side)
+// ---------------------------------------------------------------------------------------------
+__global__ void finish_kernel(const FinishArgs a) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= a.n_slots) return;
+  const int slot = a.slots[k];
+  const long long it = a.mt.iters[slot];
+  bool evict = false;
+  if (a.evict_enabled) {
+    if (!a.force_max_iter)
+      evict = (fabs(a.mt.old_fit[slot] - a.mt.fit[slot]) < a.tol) || (it >= a.max_iter);
+    else
+      evict = it >= a.max_iter;
+  }
+  if (evict)
+    a.mt.flags[slot] |= 4;
+  else
+    a.mt.iters[slot] = it + 1;
+}
+
+hipError_t finish_launch(const FinishArgs &a, hipStream_t st) {
+  if (a.n_slots <= 0) return hipSuccess;
+  hipLaunchKernelGGL(finish_kernel, dim3((a.n_slots + 127) / 128), dim3(128), 0, st, a);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// set-up kernels
+// ---------------------------------------------------------------------------------------------
+// Xp[m + Mp*(a + Ap*s)] = X[...] with the output mode `m_mode` fastest, then the inner mode
+// `a_mode`, then the remaining modes in increasing order (first fastest); pads are zero.
+struct PermArgs {
+  const double *X;
+  double *Xp;
+  int n_modes;
+  int dims[CALS_MAX_MODES];
+  long long stride[CALS_MAX_MODES];  // element stride of every mode in X
+  int m_mode, a_mode;
+  int Mp, Ap;
+  long long S;
+};
+
+__global__ void permute_pad_kernel(const PermArgs a) {
+  const long long total = (long long)a.Mp * a.Ap * a.S;
+  const int M = a.dims[a.m_mode], A = a.dims[a.a_mode];
+  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total;
+       e += (long long)gridDim.x * blockDim.x) {
+    const int m = (int)(e % a.Mp);
+    const long long t = e / a.Mp;
+    const int ai = (int)(t % a.Ap);
+    long long s = t / a.Ap;
+    double v = 0.0;
+    if (m < M && ai < A) {
+      long long off = m * a.stride[a.m_mode] + ai * a.stride[a.a_mode];
+      for (int k = 0; k < a.n_modes; ++k) {
+        if (k == a.m_mode || k == a.a_mode) continue;
+        off += (s % a.dims[k]) * a.stride[k];
+        s /= a.dims[k];
+      }
+      v = a.X[off];
+    }
+    a.Xp[e] = v;
+  }
+}
+
+hipError_t permute_pad_launch(const double *X, int n_modes, const int *dims, int m_mode,
+                              int a_mode, int Mp, int Ap, double *Xp, long long S,
+                              hipStream_t st) {
+  PermArgs a;
+  a.X = X;
+  a.Xp = Xp;
+  a.n_modes = n_modes;
+  long long str = 1;
+  for (int k = 0; k < n_modes; ++k) {
+    a.dims[k] = dims[k];
+    a.stride[k] = str;
+    str *= dims[k];
+  }
+  a.m_mode = m_mode;
+  a.a_mode = a_mode;
+  a.Mp = Mp;
+  a.Ap = Ap;
+  a.S = S;
+  hipLaunchKernelGGL(permute_pad_kernel, dim3(4096), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+
+// Sum of squares of every mode-0 slice (utils::calculate_jackknifing_norms, utils.cpp:103-152),
+// deterministic: stage 1 = n_part blocks each reduce a contiguous range of columns into
+// partial[b][i]; stage 2 = ordered sum over b.
+__global__ void slice_sumsq_stage1(const double *X, long long I, long long cols, double *partial,
+                                   int n_part) {
+  const int b = blockIdx.x;
+  const long long c0 = cols * b / n_part, c1 = cols * (b + 1) / n_part;
+  for (long long i = threadIdx.x; i < I; i += blockDim.x) {
+    double s = 0.0;
+    for (long long c = c0; c < c1; ++c) {
+      const double v = X[i + I * c];
+      s += v * v;
+    }
+    partial[(long long)b * I + i] = s;
+  }
+}
+
+__global__ void slice_sumsq_stage2(const double *partial, long long I, int n_part, double *ss) {
+  const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (i >= I) return;
+  double s = 0.0;
+  for (int b = 0; b < n_part; ++b) s += partial[(long long)b * I + i];
+  ss[i] = s;
+}
+
+hipError_t slice_sumsq_launch(const double *X, long long I, long long cols, double *partial,
+                              int n_part, double *ss_out, hipStream_t st) {
+  hipLaunchKernelGGL(slice_sumsq_stage1, dim3(n_part), dim3(256), 0, st, X, I, cols, partial,
+                     n_part);
+  hipLaunchKernelGGL(slice_sumsq_stage2, dim3((unsigned)((I + 255) / 256)), dim3(256), 0, st,
+                     partial, I, n_part, ss_out);
+  return hipGetLastError();
+}
+
+// compress: move ncols columns starting at src_col left by off columns; one block walks the
+// columns in ascending order (destination < source, so this is overlap-safe).
+__global__ void move_columns_kernel(double *buf, long long rows, long long src_col,
+                                    long long ncols, long long off) {
+  for (long long c = 0; c < ncols; ++c) {
+    const double *s = buf + rows * (src_col + c);
+    double *d = buf + rows * (src_col + c - off);
+    for (long long i = threadIdx.x; i < rows; i += blockDim.x) d[i] = s[i];
+    __syncthreads();
+  }
+}
+
+hipError_t move_columns_launch(double *buf, long long rows, long long src_col, long long ncols,
+                               long long off, hipStream_t st) {
+  if (ncols <= 0 || off <= 0) return hipSuccess;
+  hipLaunchKernelGGL(move_columns_kernel, dim3(1), dim3(256), 0, st, buf, rows, src_col, ncols,
+                     off);
+  return hipGetLastError();
+}
+
+}  // namespace calship

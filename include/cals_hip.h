@@ -1,0 +1,159 @@
+/*
+ * cals_hip.h -- C ABI of the MI355X-native Concurrent-ALS (CALS) engine (libcals_hip.so).
+ *
+ * The reference (HPAC/CP-CALS) has no FFI: its boundary for this path is the C++ function
+ *     cals::CalsReport cals::cp_cals(const Tensor&, KtensorQueue&, CalsParams&)   include/cals.h:196
+ * and the value classes Tensor / Ktensor / MultiKtensor.  This header is the plain-C layer that a
+ * binding for that boundary needs (C++ header layer: cp-cals_amd/cals/, MEX, ctypes ...): opaque
+ * handle, raw pointers and sizes, int status codes, no exceptions, no torch/HIP types.
+ * One engine per GPU, one host thread per engine.  All matrices are column-major doubles exactly
+ * as the reference's Matrix (include/matrix.h:9-23); file:line citations are relative to the
+ * reference tree.
+ */
+#ifndef CALS_HIP_H
+#define CALS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CALS_HIP_MAX_MODES 8
+#define CALS_HIP_MAX_RANK 32 /* per-model rank limit of the batched update kernels (round 1) */
+
+/* status codes */
+enum {
+  CALS_HIP_OK = 0,
+  CALS_HIP_ERR_ARG = 1,      /* bad argument (see cals_hip_last_error) */
+  CALS_HIP_ERR_HIP = 2,      /* a HIP runtime call failed; reference: cuda_utils.cpp:28-90 exit()s */
+  CALS_HIP_ERR_STATE = 3,    /* call out of order (e.g. no tensor set) */
+  CALS_HIP_ERR_FULL = 4,     /* BufferFull, include/multi_ktensor.h:123-127 */
+  CALS_HIP_ERR_NO_DEVICE = 5 /* no HIP device / kernel image not loadable: the engine never
+                                falls back to a CPU path */
+};
+
+typedef struct cals_hip_engine cals_hip_engine;
+
+/* The CalsParams fields that steer the loop (include/cals.h:138-159), same names and defaults.
+ * update_method is UNCONSTRAINED only; mttkrp_method/mttkrp_lut select among CPU variants in the
+ * reference and have no meaning here (one fused kernel family). */
+typedef struct {
+  int64_t max_iterations;   /* 200 */
+  double tol;               /* 1e-7 */
+  int line_search;          /* 0 */
+  int line_search_interval; /* 5 */
+  double line_search_step;  /* 0 => cbrt(model iteration), src/cals.cpp:317-318 */
+  int line_search_method;   /* 0 = ls::NO_ERROR_CHECKING (only method on the device path) */
+  int force_max_iter;       /* 0 */
+  int always_evict_first;   /* 0 */
+} cals_hip_params;
+
+/* CalsReport result fields (include/cals.h:27-63) + device timings (ms) from hipEvents. */
+typedef struct {
+  int64_t iter;             /* outer sweeps of the loop, CalsReport::iter */
+  int64_t n_ktensors;       /* models admitted */
+  int64_t ktensor_comp_sum; /* sum of their ranks */
+  int64_t ls_performed;
+  int64_t ls_failed;
+  double X_norm;
+  double total_ms;          /* whole cals_hip_run call (host clock) */
+  double loop_ms;           /* do{}while loop only (host clock, device synchronised) */
+} cals_hip_report;
+
+/* Per-model results that the reference keeps inside Ktensor (include/ktensor.h:27-33). */
+typedef struct {
+  int64_t iters;
+  double fit, old_fit, approx_error;
+  int evicted; /* 1 once the factors/lambda have been written back to the caller's buffers */
+} cals_hip_model_status;
+
+/* Live kernel statistics (hipEvent pairs around every launch of the named kernel on the
+ * engine's stream) gathered while profiling is enabled. */
+typedef struct {
+  int64_t mttkrp_launches;
+  double mttkrp_ms;         /* sum of launch durations */
+  double mttkrp_flops;      /* algorithmic: 2 * prod(modes) * active_cols per launch, summed */
+  int64_t update_launches;
+  double update_ms;
+  int64_t other_launches;
+  double other_ms;
+} cals_hip_kernel_stats;
+
+void cals_hip_default_params(cals_hip_params *p);
+
+/* ---- lifetime ---- */
+/* Replaces: MultiKtensor(modes, buffer_size) src/multi_ktensor.cpp:8-12 + the device set-up of
+ * cp_cals src/cals.cpp:142-167 (streams, device buffers).  buffer_size = CalsParams::buffer_size
+ * (columns of every multi-factor).  device = HIP ordinal. */
+int cals_hip_create(cals_hip_engine **out, int n_modes, const int64_t *modes, int64_t buffer_size,
+                    int device);
+int cals_hip_destroy(cals_hip_engine *e);
+const char *cals_hip_last_error(const cals_hip_engine *e);
+
+/* Replaces: X.allocate_cudata + send_to_device_async, src/cals.cpp:144-147; X.norm()
+ * include/tensor.h:196; utils::calculate_jackknifing_norms src/utils/utils.cpp:103-152.
+ * X_host: prod(modes) doubles, mode 0 fastest (include/tensor.h:173).  The engine keeps one
+ * zero-padded permuted copy per mode in HBM (layout: DESIGN.md). */
+int cals_hip_set_tensor(cals_hip_engine *e, const double *X_host);
+
+int cals_hip_set_params(cals_hip_engine *e, const cals_hip_params *p);
+
+/* ---- the KtensorQueue ---- */
+/* Replaces: kt_queue.emplace(ktensor) by the callers (src/examples/driver.cpp:177-180).
+ * factors[n]: I_n x rank col-major (ld = I_n), lambda: rank doubles; both are read at admission
+ * and overwritten at eviction (Ktensor::attach/detach, src/ktensor.cpp:109-135) and must stay
+ * valid until cals_hip_run returns.  jk_mode < 0: regular model; else the model is a jackknife
+ * replica (Ktensor jk ctor include/ktensor.h:83-88).  ticket: handle for cals_hip_model_result. */
+int cals_hip_enqueue(cals_hip_engine *e, int64_t rank, double *const *factors, double *lambda,
+                     int jk_mode, int64_t jk_fiber, int64_t *ticket);
+
+/* Replaces: the whole cp_cals do{}while loop, src/cals.cpp:174-382: admission, per-mode MTTKRP +
+ * update, error, line search, eviction, compress, until queue and registry are empty. */
+int cals_hip_run(cals_hip_engine *e, cals_hip_report *rep);
+
+int cals_hip_model_result(const cals_hip_engine *e, int64_t ticket, cals_hip_model_status *st);
+
+/* ---- step-wise control (what cals_hip_run is made of; used by bench.py and the tests) ---- */
+/* Admission phase only, src/cals.cpp:182-192: first-fit placement, H2D of the model's columns,
+ * Gramians, iters = 1.  n_admitted may be NULL. */
+int cals_hip_admit(cals_hip_engine *e, int64_t *n_admitted);
+/* n_sweeps ALS sweeps over the in-flight models (src/cals.cpp:203-331: LS snapshot, per-mode
+ * MTTKRP + update, error/fit, line search, then iters++ for every model) WITHOUT eviction:
+ * the caller guarantees no model reaches max_iterations or converges meanwhile (bench: force_max_iter). */
+int cals_hip_sweep(cals_hip_engine *e, int64_t n_sweeps);
+/* Eviction + compress phase, src/cals.cpp:336-362, applied to the current status. */
+int cals_hip_evict(cals_hip_engine *e, int64_t *n_evicted);
+int64_t cals_hip_active_cols(const cals_hip_engine *e);  /* mkt.get_factor(0).get_cols() */
+int64_t cals_hip_models_in_flight(const cals_hip_engine *e);
+int64_t cals_hip_queue_size(const cals_hip_engine *e);
+int cals_hip_synchronize(cals_hip_engine *e);
+
+/* ---- inspection (tests) ---- */
+/* MTTKRP of the current multi-factor block for `mode` (mttkrp::mttkrp, src/utils/mttkrp.cpp:562)
+ * into G_host (I_mode x active_cols, ld = I_mode) WITHOUT touching the engine state. */
+int cals_hip_debug_mttkrp(cals_hip_engine *e, int mode, double *G_host);
+/* Copy multi-factor `mode` (I_mode x active_cols) / lambda (active_cols) / the column-indexed
+ * Gramian store (CALS_HIP_MAX_RANK x active_cols per mode) to the host. */
+int cals_hip_debug_get_factor(cals_hip_engine *e, int mode, double *host);
+int cals_hip_debug_get_lambda(cals_hip_engine *e, double *host);
+int cals_hip_debug_get_gramian(cals_hip_engine *e, int mode, double *host);
+/* Status of an in-flight model (by ticket) as the device currently holds it. */
+int cals_hip_debug_model_status(cals_hip_engine *e, int64_t ticket, cals_hip_model_status *st,
+                                int64_t *col);
+/* jackknife norms / X norm computed on the device at set_tensor */
+int cals_hip_debug_get_norms(cals_hip_engine *e, double *X_norm, double *jk_norms /* modes[0] or NULL */);
+
+/* ---- measurement ---- */
+int cals_hip_set_profiling(cals_hip_engine *e, int enabled);
+int cals_hip_get_kernel_stats(cals_hip_engine *e, cals_hip_kernel_stats *out);
+int cals_hip_reset_kernel_stats(cals_hip_engine *e);
+/* hipStream_t the engine launches on (as void*), so callers can bracket it with their own events */
+void *cals_hip_stream(cals_hip_engine *e);
+/* number of HIP devices visible (0 when none); never initialises a context on failure */
+int cals_hip_device_count(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CALS_HIP_H */
