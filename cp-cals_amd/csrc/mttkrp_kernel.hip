@@ -33,7 +33,7 @@ struct MtCfg {
   static constexpr int LDL = (MT % 2 == 1) ? 16 * MT : 16 * MT + 16;  // LDS leading dim (doubles)
   static constexpr int SLAB = 16 * LDL;                               // doubles per unit slab
   static constexpr int PIECES = LDL / 8;                              // 1 KiB DMA pieces per slab
-  static constexpr int SB_RAW = (78 * 1024) / (SLAB * 8);
+  static constexpr int SB_RAW = (80 * 1024) / ((SLAB + CALS_BN) * 8);  // 2 stages <= 160 KiB
   static constexpr int SB = SB_RAW < 1 ? 1 : (SB_RAW > 8 ? 8 : SB_RAW);  // units per stage
   static constexpr int STAGE = SLAB * SB;
   static constexpr int QSTAGE = SB * CALS_BN;                         // Q values per stage

@@ -59,6 +59,9 @@ def lib():
         _LIB = C.CDLL(build())
         _LIB.or_norm.restype = C.c_double
         _LIB.or_fast_error.restype = C.c_double
+        # parity runs are single-threaded and deterministic; the cpu_baseline leg raises this.
+        # (OpenMP regions on a many-core host cost more than the tiny per-model loops they wrap.)
+        _LIB.or_set_threads(1)
     return _LIB
 
 
