@@ -63,6 +63,7 @@ EXPORTS = [
     "cals_hip_debug_get_lambda", "cals_hip_debug_get_gramian", "cals_hip_debug_model_status",
     "cals_hip_debug_get_norms", "cals_hip_set_profiling", "cals_hip_get_kernel_stats",
     "cals_hip_reset_kernel_stats", "cals_hip_stream", "cals_hip_device_count",
+    "cals_hip_host_first_fit", "cals_hip_host_compress_plan", "cals_hip_host_active_cols",
 ]
 
 _LIB = None
@@ -106,8 +107,35 @@ def load_library():
     lib.cals_hip_stream.argtypes = [vp]
     lib.cals_hip_stream.restype = vp
     lib.cals_hip_device_count.restype = C.c_int
+    pi64 = C.POINTER(i64)
+    lib.cals_hip_host_first_fit.argtypes = [pi64, i64, i64]
+    lib.cals_hip_host_first_fit.restype = i64
+    lib.cals_hip_host_compress_plan.argtypes = [pi64, i64, pi64, pi64, i64]
+    lib.cals_hip_host_compress_plan.restype = i64
+    lib.cals_hip_host_active_cols.argtypes = [pi64, i64]
+    lib.cals_hip_host_active_cols.restype = i64
     _LIB = lib
     return lib
+
+
+def host_first_fit(occupancy, rank):
+    occ = np.ascontiguousarray(occupancy, dtype=np.int64)
+    return load_library().cals_hip_host_first_fit(occ.ctypes.data_as(C.POINTER(C.c_int64)), occ.size, int(rank))
+
+
+def host_compress_plan(occupancy):
+    occ = np.ascontiguousarray(occupancy, dtype=np.int64)
+    ids = np.zeros(occ.size, dtype=np.int64)
+    offs = np.zeros(occ.size, dtype=np.int64)
+    p = C.POINTER(C.c_int64)
+    n = load_library().cals_hip_host_compress_plan(occ.ctypes.data_as(p), occ.size, ids.ctypes.data_as(p),
+                                                   offs.ctypes.data_as(p), occ.size)
+    return list(zip(ids[:n].tolist(), offs[:n].tolist()))
+
+
+def host_active_cols(occupancy):
+    occ = np.ascontiguousarray(occupancy, dtype=np.int64)
+    return load_library().cals_hip_host_active_cols(occ.ctypes.data_as(C.POINTER(C.c_int64)), occ.size)
 
 
 def default_params(**kw):

@@ -144,33 +144,53 @@ int dev_alloc(cals_hip_engine *e, T **p, size_t n) {
 }
 
 // MultiKtensor::adjust_edges, src/multi_ktensor.cpp:165-186 (cell 0 is never examined)
-void adjust_edges(cals_hip_engine *e) {
-  int64_t end = e->buffer;
+int64_t active_cols_of(const int64_t *occ, int64_t n) {
+  int64_t end = n;
   for (int64_t i = end - 1; i > 0; i--) {
-    if (e->occ[i] == 0)
+    if (occ[i] == 0)
       end--;
     else
       break;
   }
-  e->end = end;
+  return end;
 }
+void adjust_edges(cals_hip_engine *e) { e->end = active_cols_of(e->occ.data(), e->buffer); }
 
 // MultiKtensor::check_availability, src/multi_ktensor.cpp:14-39
-int64_t check_availability(const cals_hip_engine *e, int64_t rank) {
+int64_t first_fit(const int64_t *occ, int64_t n, int64_t rank) {
   int64_t comp_counter = 0, pos_index = -1, prev_occ = -1;
-  for (int64_t i = 0; i < e->buffer; i++) {
+  for (int64_t i = 0; i < n; i++) {
     if (comp_counter == rank) break;
-    if (e->occ[i] == 0 && prev_occ != 0) {
+    if (occ[i] == 0 && prev_occ != 0) {
       pos_index = i;
       comp_counter++;
-    } else if (e->occ[i] == 0 && prev_occ == 0)
+    } else if (occ[i] == 0 && prev_occ == 0)
       comp_counter++;
     else
       comp_counter = 0;
-    prev_occ = e->occ[i];
+    prev_occ = occ[i];
   }
   if (pos_index == -1 || comp_counter != rank) return -1;
   return pos_index;
+}
+int64_t check_availability(const cals_hip_engine *e, int64_t rank) {
+  return first_fit(e->occ.data(), e->buffer, rank);
+}
+
+// move list of MultiKtensor::compress, src/multi_ktensor.cpp:196-209
+void compress_plan(const int64_t *occ, int64_t n, std::vector<std::pair<int64_t, int64_t>> &req) {
+  int64_t col_offset = 0, added = -1;
+  for (int64_t c = 0; c < n; c++) {
+    const int64_t cell = occ[c];
+    if (cell == added)
+      continue;
+    else if (cell == 0)
+      col_offset++;
+    else if (col_offset != 0) {
+      req.emplace_back(cell, col_offset);
+      added = cell;
+    }
+  }
 }
 
 // ---- profiling helpers ----
@@ -438,19 +458,8 @@ int remove_model(cals_hip_engine *e, int64_t ticket) {
 
 // MultiKtensor::compress, src/multi_ktensor.cpp:188-264
 int compress(cals_hip_engine *e) {
-  int64_t col_offset = 0, added = -1;
   std::vector<std::pair<int64_t, int64_t>> req;
-  for (int64_t c = 0; c < e->buffer; c++) {
-    const int64_t cell = e->occ[c];
-    if (cell == added)
-      continue;
-    else if (cell == 0)
-      col_offset++;
-    else if (col_offset != 0) {
-      req.emplace_back(cell, col_offset);
-      added = cell;
-    }
-  }
+  compress_plan(e->occ.data(), e->buffer, req);
   if (req.empty()) {
     adjust_edges(e);
     return CALS_HIP_OK;
@@ -1019,5 +1028,27 @@ int cals_hip_reset_kernel_stats(cals_hip_engine *e) {
 }
 
 void *cals_hip_stream(cals_hip_engine *e) { return e ? (void *)e->stream : nullptr; }
+
+int64_t cals_hip_host_first_fit(const int64_t *occupancy, int64_t n_cols, int64_t rank) {
+  if (!occupancy || n_cols < 1 || rank < 1) return -1;
+  return first_fit(occupancy, n_cols, rank);
+}
+
+int64_t cals_hip_host_compress_plan(const int64_t *occupancy, int64_t n_cols, int64_t *ids,
+                                    int64_t *offsets, int64_t max_moves) {
+  if (!occupancy || n_cols < 1) return 0;
+  std::vector<std::pair<int64_t, int64_t>> req;
+  compress_plan(occupancy, n_cols, req);
+  for (int64_t i = 0; i < (int64_t)req.size() && i < max_moves; i++) {
+    if (ids) ids[i] = req[(size_t)i].first;
+    if (offsets) offsets[i] = req[(size_t)i].second;
+  }
+  return (int64_t)req.size();
+}
+
+int64_t cals_hip_host_active_cols(const int64_t *occupancy, int64_t n_cols) {
+  if (!occupancy || n_cols < 1) return 0;
+  return active_cols_of(occupancy, n_cols);
+}
 
 }  // extern "C"

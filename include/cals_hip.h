@@ -144,6 +144,18 @@ int cals_hip_debug_model_status(cals_hip_engine *e, int64_t ticket, cals_hip_mod
 /* jackknife norms / X norm computed on the device at set_tensor */
 int cals_hip_debug_get_norms(cals_hip_engine *e, double *X_norm, double *jk_norms /* modes[0] or NULL */);
 
+/* ---- host logic of MultiKtensor, exposed so that it can be tested without a GPU ---- */
+/* MultiKtensor::check_availability (src/multi_ktensor.cpp:14-39) on an occupancy vector (id per
+ * column, 0 = free): first column of the first free run of `rank` columns, or -1 (BufferFull). */
+int64_t cals_hip_host_first_fit(const int64_t *occupancy, int64_t n_cols, int64_t rank);
+/* MultiKtensor::compress move list (src/multi_ktensor.cpp:196-209): for every model that has free
+ * columns to its left, (id, offset); returns the number of moves (at most max_moves written). */
+int64_t cals_hip_host_compress_plan(const int64_t *occupancy, int64_t n_cols, int64_t *ids,
+                                    int64_t *offsets, int64_t max_moves);
+/* MultiKtensor::adjust_edges (src/multi_ktensor.cpp:165-186): active width = last occupied
+ * column + 1, never below 1 (cell 0 is not examined). */
+int64_t cals_hip_host_active_cols(const int64_t *occupancy, int64_t n_cols);
+
 /* ---- measurement ---- */
 int cals_hip_set_profiling(cals_hip_engine *e, int enabled);
 int cals_hip_get_kernel_stats(cals_hip_engine *e, cals_hip_kernel_stats *out);

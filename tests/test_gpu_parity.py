@@ -1,0 +1,275 @@
+"""Parity tests proper: the HIP path, called through the C ABI, against the CPU oracle on the same
+seeded inputs, against the committed golden vectors, and (at BASELINE.json's full sizes) through
+size-independent properties.  Tolerances (fp64, stated by BASELINE.json north_star): factors and
+lambda within 1e-8 relative Frobenius of the reference path after the same number of sweeps; single
+kernels are held to 1e-12."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import make_models, numpy_mttkrp, reconstruct, rel
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+TOL_KERNEL = 1e-12
+TOL_RUN = 1e-8
+
+
+def engine_with(cc, inputs, modes, ranks, X, seed=1, jk=None, buffer=None, params=None):
+    base = make_models(inputs, modes, ranks, seed=seed, jk=jk)
+    e = cc.Engine(modes, sum(ranks) if buffer is None else buffer)
+    e.set_tensor(X)
+    if params is not None:
+        e.set_params(params)
+    gm = [cc.Model(fs, lam, jk=j) for fs, lam, j in base]
+    for m in gm:
+        e.enqueue(m)
+    return e, gm, base
+
+
+def test_native_library_is_the_one_running(cc):
+    lib = cc.load_library()
+    assert lib.cals_hip_device_count() >= 1
+    with open("/proc/self/maps") as f:
+        assert "libcals_hip.so" in f.read()
+
+
+@pytest.mark.parametrize("modes,ranks", [
+    ([20, 20, 20], [2, 3, 4, 5]),            # BASELINE config 1
+    ([7, 5, 3], [1, 2, 3]),                  # tiny, ragged
+    ([13, 12, 11], list(range(1, 13))),      # reference test shape
+    ([100, 37, 41], None),                   # non-cubic, 20 models ranks 1..20
+    ([299, 301, 41], None),                  # BASELINE config 4 shape
+    ([330, 17, 9], [5, 20, 7]),              # more than 20 m-tiles: two M blocks
+    ([40, 30, 20], [20] * 21),               # R = 420: four column blocks
+    ([3, 3, 3, 3], [7, 2]),                  # 4-way (reference ComputeCorrectResult4D shape)
+    ([6, 5, 4, 3], [3, 4, 5]),
+    ([4, 3, 5, 2, 3], [2, 3]),               # 5-way
+])
+def test_mttkrp_every_mode_vs_oracle(cc, oracle, inputs, modes, ranks):
+    if ranks is None:
+        ranks = inputs.ranks_1_to_20(20 if modes[0] == 100 else 10)
+    X = inputs.tensor(modes, 0)
+    e, gm, base = engine_with(cc, inputs, modes, ranks, X)
+    e.admit()
+    facs = [np.asfortranarray(np.hstack([fs[n] for fs, _, _ in base])) for n in range(len(modes))]
+    for n in range(len(modes)):
+        G = e.debug_mttkrp(n)
+        assert rel(G, oracle.mttkrp(X, modes, facs, n, oracle.MTTKRP)) < TOL_KERNEL
+        if len(modes) == 3:  # the reference's other variants agree too (test_als.cpp:10-60)
+            assert rel(G, oracle.mttkrp(X, modes, facs, n, oracle.TWOSTEP1)) < TOL_KERNEL
+    e.close()
+
+
+def test_mttkrp_golden(cc, inputs):
+    gold = np.load(os.path.join(GOLD, "mttkrp.npz"))
+    for modes, ranks in (([7, 5, 3], [1, 2, 3]), ([3, 3, 3, 3], [7, 2]), ([40, 30, 20], [20] * 7)):
+        X = inputs.tensor(modes, 0)
+        e, _, _ = engine_with(cc, inputs, modes, ranks, X)
+        e.admit()
+        tag = "x".join(str(m) for m in modes)
+        for n in range(len(modes)):
+            assert rel(e.debug_mttkrp(n), gold["%s_mode%d" % (tag, n)]) < TOL_KERNEL
+        e.close()
+
+
+def test_tensor_norms(cc, oracle, inputs):
+    modes = [23, 7, 11]
+    X = inputs.tensor(modes, 5)
+    e = cc.Engine(modes, 8)
+    e.set_tensor(X)
+    xn, jk = e.debug_norms()
+    assert abs(xn - np.linalg.norm(X)) / np.linalg.norm(X) < 1e-14
+    assert rel(jk, oracle.jk_norms(X, modes)) < 1e-14
+    e.close()
+
+
+@pytest.mark.parametrize("ranks", [[1], [2], [5], [20], [32], [1, 20, 7, 32, 13]])
+def test_single_sweep_state_vs_oracle(cc, oracle, inputs, ranks):
+    """One sweep: factors, lambda, Gramians, error, fit of every model (update kernel unit test
+    through the public path; ranks cover every register class of the kernel, 32 = the limit)."""
+    modes = [40, 36, 33]
+    X = inputs.tensor(modes, 6)
+    prm = cc.default_params(max_iterations=100, force_max_iter=1)
+    e, gm, base = engine_with(cc, inputs, modes, ranks, X, params=prm)
+    e.admit()
+    e.sweep(2)
+    om = [oracle.Model(fs, lam) for fs, lam, _ in base]
+    oracle.cp_cals(X, modes, om, oracle.default_params(max_iterations=2, force_max_iter=1,
+                                                       buffer_size=sum(ranks), mttkrp_method=oracle.MTTKRP))
+    lam = e.debug_lambda()
+    col = 0
+    for m, g in zip(om, gm):
+        r = m.rank
+        for n in range(3):
+            F = e.debug_factor(n)[:, col:col + r]
+            assert rel(F, m.factors[n]) < TOL_KERNEL
+            Gm = e.debug_gramian(n)[:r, col:col + r]
+            assert rel(Gm, m.factors[n].T @ m.factors[n]) < TOL_KERNEL
+        assert rel(lam[col:col + r], m.lam) < TOL_KERNEL
+        st, c = e.debug_status(g)
+        assert c == col and st.iters == 3  # admitted at 1, two sweeps survived
+        assert abs(st.approx_error - m.error) <= 1e-10 * max(1.0, m.error)
+        assert abs(st.fit - m.fit) <= 1e-12
+        col += r
+    e.close()
+
+
+def test_update_golden(cc, inputs):
+    """update kernel against the committed unit vectors is covered through whole runs below; here:
+    the c1 golden case at 1, 2, 3, 10, 50 forced iterations (BASELINE config 1)."""
+    gold = np.load(os.path.join(GOLD, "c1_20cube.npz"))
+    modes, ranks = [20, 20, 20], [2, 3, 4, 5]
+    X = inputs.tensor(modes, 0)
+    for it in (1, 2, 3, 10, 50):
+        prm = cc.default_params(max_iterations=it, force_max_iter=1)
+        e, gm, _ = engine_with(cc, inputs, modes, ranks, X, params=prm)
+        rep = e.run()
+        assert rep.iter == gold["it%d_sweeps" % it][0]
+        assert [m.iters for m in gm] == list(gold["it%d_iters" % it])
+        for n in range(3):
+            assert rel(np.hstack([m.factors[n] for m in gm]), gold["it%d_factor%d" % (it, n)]) < TOL_RUN
+        assert rel(np.concatenate([m.lam for m in gm]), gold["it%d_lambda" % it]) < TOL_RUN
+        assert np.allclose([m.error for m in gm], gold["it%d_error" % it], rtol=1e-9, atol=1e-12)
+        e.close()
+
+
+def _run_both(cc, oracle, inputs, modes, ranks, X, iters, jk=None, buffer=None, **kw):
+    force = kw.pop("force_max_iter", 1)
+    prm = cc.default_params(max_iterations=iters, force_max_iter=force, **kw)
+    e, gm, base = engine_with(cc, inputs, modes, ranks, X, jk=jk, buffer=buffer, params=prm)
+    rep = e.run()
+    e.close()
+    om = [oracle.Model(fs, lam, jk=j) for fs, lam, j in base]
+    po = oracle.default_params(max_iterations=iters, force_max_iter=force, mttkrp_method=oracle.MTTKRP,
+                               buffer_size=sum(ranks) if buffer is None else buffer, **kw)
+    ro = oracle.cp_cals(X, modes, om, po)
+    return gm, om, rep, ro
+
+
+def _assert_models_match(gm, om, tol=TOL_RUN):
+    for a, b in zip(gm, om):
+        assert a.iters == b.iters
+        for fa, fb in zip(a.factors, b.factors):
+            assert rel(fa, fb) < tol
+        assert rel(a.lam, b.lam) < tol
+        if b.error < 1e300:
+            assert abs(a.error - b.error) <= 1e-7 * max(1.0, abs(b.error))
+            assert abs(a.fit - b.fit) <= 1e-7
+
+
+@pytest.mark.parametrize("modes,ranks,iters", [
+    ([20, 20, 20], [2, 3, 4, 5], 50),
+    ([13, 12, 11], list(range(1, 13)) * 3, 30),
+    ([6, 5, 4, 3], [3, 4, 5], 10),
+    ([50, 40, 30], None, 10),
+])
+def test_forced_iterations_vs_oracle(cc, oracle, inputs, modes, ranks, iters):
+    if ranks is None:
+        ranks = inputs.ranks_1_to_20(40)
+    X = inputs.tensor(modes, 3)
+    gm, om, rep, ro = _run_both(cc, oracle, inputs, modes, ranks, X, iters)
+    assert rep.iter == ro.iter == iters
+    assert (rep.n_ktensors, rep.ktensor_comp_sum) == (ro.n_ktensors, ro.ktensor_comp_sum)
+    _assert_models_match(gm, om)
+
+
+def test_jackknife_models_vs_oracle_and_golden(cc, oracle, inputs):
+    modes, comp = [20, 9, 12], 5
+    X = inputs.low_rank_tensor(modes, comp, seed=21)[0]
+    jk = [(0, i) for i in range(20)]
+    gm, om, rep, ro = _run_both(cc, oracle, inputs, modes, [comp] * 20, X, 20, jk=jk)
+    _assert_models_match(gm, om)
+    for i, m in enumerate(gm):
+        assert np.all(m.factors[0][i, :] == 0.0)  # the jk fiber stays exactly zero
+
+
+def test_line_search_vs_oracle(cc, oracle, inputs):
+    modes, ranks = [20, 20, 20], [2, 3, 4, 5, 20, 17]
+    X = inputs.tensor(modes, 3)
+    gm, om, rep, ro = _run_both(cc, oracle, inputs, modes, ranks, X, 25, line_search=1,
+                                line_search_interval=5)
+    assert (rep.ls_performed, rep.ls_failed) == (ro.ls_performed, ro.ls_failed)
+    assert rep.ls_performed > 0
+    _assert_models_match(gm, om)
+
+
+@pytest.mark.parametrize("ls", [0, 1])
+def test_queue_eviction_compress_vs_oracle(cc, oracle, inputs, ls):
+    """buffer_size < sum of ranks, tol-based convergence: admission order, eviction sweep, compress
+    (restated SimpleCorrectness / LineSearchCorrectness, tests/cals/test_cals.cpp:13-179)."""
+    modes = [13, 12, 11]
+    ranks = [r for r in range(1, 13) for _ in range(5)]
+    X = inputs.low_rank_tensor(modes, 10, seed=9)[0]
+    gm, om, rep, ro = _run_both(cc, oracle, inputs, modes, ranks, X, 200, buffer=30, tol=1e-5,
+                                force_max_iter=0, line_search=ls, line_search_interval=10)
+    assert rep.iter == ro.iter
+    assert (rep.ls_performed, rep.ls_failed) == (ro.ls_performed, ro.ls_failed)
+    for a, b in zip(gm, om):
+        assert a.iters == b.iters
+        # reference criterion: reconstructed tensors agree (MODEL_DIFF_ACC, test_cals.cpp:7,81-84)
+        d = np.linalg.norm(reconstruct(a.factors, a.lam, modes) - reconstruct(b.factors, b.lam, modes))
+        assert d <= 1e-9
+
+
+def test_rejects_bad_input_loudly(cc, inputs):
+    e = cc.Engine([8, 8, 8], 16)
+    fs = [np.zeros((8, 40), order="F")] * 3
+    with pytest.raises(cc.CalsHipError):
+        e.enqueue(cc.Model(fs, np.ones(40)))         # rank > CALS_HIP_MAX_RANK / buffer
+    with pytest.raises(cc.CalsHipError):
+        e.sweep(1)                                     # no tensor yet
+    with pytest.raises(cc.CalsHipError):
+        e.set_params(cc.default_params(line_search=1, line_search_method=1))
+    e.close()
+
+
+# ---- full-size properties (BASELINE configs 2 and 3): no oracle run, exact identities instead ----
+def test_full_size_c3_mttkrp_identities(cc, inputs):
+    """300^3 fp64, 256 models ranks 1..20 (R = 2656): (1) columns of a model that is all-ones give
+    the mode sums of X; (2) linearity: MTTKRP of a doubled factor doubles G exactly."""
+    modes = [300, 300, 300]
+    X = inputs.tensor(modes, 0)
+    ranks = inputs.ranks_1_to_20(256)
+    base = make_models(inputs, modes, ranks)
+    base[0][0][0][:] = 1.0
+    base[0][0][1][:] = 1.0
+    base[0][0][2][:] = 1.0
+    e = cc.Engine(modes, sum(ranks))
+    e.set_tensor(X)
+    models = [cc.Model(fs, lam) for fs, lam, _ in base]
+    for m in models:
+        e.enqueue(m)
+    e.admit()
+    X3 = X.reshape(modes, order="F")
+    G0 = e.debug_mttkrp(0)
+    G1 = e.debug_mttkrp(1)
+    G2 = e.debug_mttkrp(2)
+    assert rel(G0[:, 0], X3.sum(axis=(1, 2))) < 1e-12
+    assert rel(G1[:, 0], X3.sum(axis=(0, 2))) < 1e-12
+    assert rel(G2[:, 0], X3.sum(axis=(0, 1))) < 1e-12
+    # spot-check 3 random columns against the einsum formulation
+    rng = np.random.default_rng(0)
+    facs = [np.hstack([fs[n] for fs, _, _ in base]) for n in range(3)]
+    for c in rng.integers(1, sum(ranks), size=3):
+        want = np.einsum("ijk,j,k->i", X3, facs[1][:, c], facs[2][:, c])
+        assert rel(G0[:, c], want) < 1e-11
+        want = np.einsum("ijk,i,j->k", X3, facs[0][:, c], facs[1][:, c])
+        assert rel(G2[:, c], want) < 1e-11
+    e.close()
+
+
+def test_full_size_c2_fast_error_is_true_error(cc, inputs):
+    """100^3, 64 models ranks 1..20, 5 sweeps: the device's fast error equals the brute-force
+    ||X - reconstruction|| (reference ComputeCorrectError, test_als.cpp:125-145)."""
+    modes = [100, 100, 100]
+    X = inputs.tensor(modes, 0)
+    ranks = inputs.ranks_1_to_20(64)
+    prm = cc.default_params(max_iterations=5, force_max_iter=1)
+    e, gm, _ = engine_with(cc, inputs, modes, ranks, X, params=prm)
+    e.run()
+    e.close()
+    for m in gm[::7]:
+        slow = np.linalg.norm(X - reconstruct(m.factors, m.lam, modes))
+        assert abs(m.error - slow) <= 1e-9 * slow

@@ -1,0 +1,56 @@
+"""The N>1 path on CPU: world_size-2 gloo processes run the sharding / aggregation logic that
+bench.py uses around the per-GPU engines (no data-path collective exists in this path)."""
+import os
+import socket
+import sys
+
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    import cp_cals_amd  # noqa: F401
+    from cp_cals_amd import sharding
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n_models = sharding.weak_scaling_models(5, world) + 1  # 11: uneven on purpose
+    mine = sharding.shard_round_robin(n_models, world, rank)
+    gathered = [None] * world
+    dist.all_gather_object(gathered, mine)
+    sharding.barrier()
+    rate, t = sharding.aggregate_rate(local_units=10 * (rank + 1), local_seconds=1.0 + rank)
+    q.put((rank, mine, gathered, rate, t))
+    dist.destroy_process_group()
+
+
+def test_round_robin_shards_and_aggregation_world2():
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    all_models = sorted(sum((r[1] for r in res), []))
+    assert all_models == list(range(11))            # a partition: nothing lost, nothing doubled
+    assert res[0][1] == [0, 2, 4, 6, 8, 10] and res[1][1] == [1, 3, 5, 7, 9]
+    for r in res:
+        assert r[2] == [res[0][1], res[1][1]]
+        assert abs(r[3] - 30.0 / 2.0) < 1e-12          # (10 + 20) units / max(1 s, 2 s)
+        assert abs(r[4] - 2.0) < 1e-12
