@@ -385,6 +385,8 @@ int sweep_once(cals_hip_engine *e, bool evict_enabled) {
     u.X_norm = e->X_norm;
     u.jk_norms = e->d_jk_norms;
     const int pk = prof_begin(e, 1, 0);
+    HIPCHK(reduce_partials_launch(e->partial, g.T, e->lay[n].ldPart, (int)e->modes[n], (int)R,
+                                  e->factor[n], e->stream));
     HIPCHK(update_launch(u, CALS_RMAX, e->stream));
     prof_end(e, pk);
   }
@@ -496,7 +498,8 @@ int compress(cals_hip_engine *e) {
 
 int admit(cals_hip_engine *e, int64_t *n_admitted) {
   int64_t count = 0;
-  std::vector<int> new_slots;
+  std::vector<int> new_slots, desc;
+  std::vector<int64_t> admitted;
   while (!e->queue.empty()) {
     const int64_t ticket = e->queue.front();
     HostModel &m = e->models[ticket];
@@ -509,46 +512,58 @@ int admit(cals_hip_engine *e, int64_t *n_admitted) {
     m.id = e->unique_id++;
     m.state = 1;
     for (int64_t i = 0; i < m.rank; i++) e->occ[pos + i] = m.id;
-    // Ktensor::attach: copy the model's factors into the buffer columns
-    for (int n = 0; n < e->n_modes; n++)
-      HIPCHK(hipMemcpyAsync(e->factor[n] + e->modes[n] * pos, m.factors[n],
-                            sizeof(double) * (size_t)(e->modes[n] * m.rank),
-                            hipMemcpyHostToDevice, e->stream));
-    HIPCHK(hipMemcpyAsync(e->lambda + pos, m.lambda, sizeof(double) * (size_t)m.rank,
-                          hipMemcpyHostToDevice, e->stream));
-    // per-slot scalars
-    const int col32 = (int)pos, rank32 = (int)m.rank, jm = m.jk_mode, jf = (int)m.jk_fiber;
-    const long long one = 1;
-    const int zero = 0;
-    const double dz = 0.0;
-    HIPCHK(hipMemcpyAsync(e->mt.col + m.slot, &col32, sizeof(int), hipMemcpyHostToDevice, e->stream));
-    HIPCHK(hipMemcpyAsync(e->mt.rank + m.slot, &rank32, sizeof(int), hipMemcpyHostToDevice, e->stream));
-    HIPCHK(hipMemcpyAsync(e->mt.iters + m.slot, &one, sizeof(long long), hipMemcpyHostToDevice, e->stream));
-    HIPCHK(hipMemcpyAsync(e->mt.jk_mode + m.slot, &jm, sizeof(int), hipMemcpyHostToDevice, e->stream));
-    HIPCHK(hipMemcpyAsync(e->mt.jk_fiber + m.slot, &jf, sizeof(int), hipMemcpyHostToDevice, e->stream));
-    HIPCHK(hipMemcpyAsync(e->mt.err + m.slot, &dz, sizeof(double), hipMemcpyHostToDevice, e->stream));
-    HIPCHK(hipMemcpyAsync(e->mt.fit + m.slot, &dz, sizeof(double), hipMemcpyHostToDevice, e->stream));
-    HIPCHK(hipMemcpyAsync(e->mt.old_fit + m.slot, &dz, sizeof(double), hipMemcpyHostToDevice, e->stream));
-    HIPCHK(hipMemcpyAsync(e->mt.ls_iter + m.slot, &zero, sizeof(int), hipMemcpyHostToDevice, e->stream));
-    HIPCHK(hipMemcpyAsync(e->mt.ls_updated_last + m.slot, &zero, sizeof(int), hipMemcpyHostToDevice, e->stream));
-    HIPCHK(hipMemcpyAsync(e->mt.flags + m.slot, &zero, sizeof(int), hipMemcpyHostToDevice, e->stream));
-    HIPCHK(hipStreamSynchronize(e->stream));  // stack temporaries above
     if (m.jk_mode >= 0) e->flag_jk = true;
     e->registry.push_back(ticket);
     e->queue.pop_front();
     e->n_ktensors++;
     e->comp_sum += m.rank;
     new_slots.push_back(m.slot);
+    desc.insert(desc.end(), {m.slot, (int)pos, (int)m.rank, m.jk_mode, (int)m.jk_fiber});
+    admitted.push_back(ticket);
     count++;
     adjust_edges(e);
   }
-  if (!new_slots.empty()) {
+  if (!admitted.empty()) {
     e->slots_dirty = true;
-    // Gramians of the new models, all modes (multi_ktensor.cpp:88-94)
-    int *d_new = nullptr;
+    // Ktensor::attach: copy the models' factors into the buffer columns.  Models admitted back to
+    // back sit in adjacent columns, so each run goes up as ONE H2D per mode from a staging buffer.
+    size_t k0 = 0;
+    std::vector<double> stage;
+    while (k0 < admitted.size()) {
+      size_t k1 = k0 + 1;
+      int64_t cols = e->models[admitted[k0]].rank;
+      while (k1 < admitted.size() &&
+             e->models[admitted[k1]].col == e->models[admitted[k0]].col + cols) {
+        cols += e->models[admitted[k1]].rank;
+        k1++;
+      }
+      const int64_t col0 = e->models[admitted[k0]].col;
+      for (int n = 0; n <= e->n_modes; n++) {  // n == n_modes: lambda
+        const int64_t rows = (n < e->n_modes) ? e->modes[n] : 1;
+        stage.resize((size_t)(rows * cols));
+        size_t off = 0;
+        for (size_t k = k0; k < k1; k++) {
+          const HostModel &m = e->models[admitted[k]];
+          const double *src = (n < e->n_modes) ? m.factors[n] : m.lambda;
+          std::memcpy(stage.data() + off, src, sizeof(double) * (size_t)(rows * m.rank));
+          off += (size_t)(rows * m.rank);
+        }
+        double *dst = (n < e->n_modes) ? e->factor[n] + rows * col0 : e->lambda + col0;
+        HIPCHK(hipMemcpyAsync(dst, stage.data(), sizeof(double) * stage.size(),
+                              hipMemcpyHostToDevice, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));  // stage is reused
+      }
+      k0 = k1;
+    }
+    // per-slot scalars + Gramians of the new models, all modes (multi_ktensor.cpp:88-96)
+    int *d_desc = nullptr, *d_new = nullptr;
+    HIPCHK(hipMalloc((void **)&d_desc, desc.size() * sizeof(int)));
     HIPCHK(hipMalloc((void **)&d_new, new_slots.size() * sizeof(int)));
+    HIPCHK(hipMemcpyAsync(d_desc, desc.data(), desc.size() * sizeof(int), hipMemcpyHostToDevice,
+                          e->stream));
     HIPCHK(hipMemcpyAsync(d_new, new_slots.data(), new_slots.size() * sizeof(int),
                           hipMemcpyHostToDevice, e->stream));
+    HIPCHK(init_slots_launch(d_desc, (int)new_slots.size(), e->mt, e->stream));
     GramInitArgs g{};
     g.slots = d_new;
     g.n_slots = (int)new_slots.size();
@@ -561,6 +576,7 @@ int admit(cals_hip_engine *e, int64_t *n_admitted) {
     g.n_modes = e->n_modes;
     HIPCHK(gram_init_launch(g, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipFree(d_desc));
     HIPCHK(hipFree(d_new));
   }
   if (n_admitted) *n_admitted = count;

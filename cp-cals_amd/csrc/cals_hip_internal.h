@@ -79,6 +79,11 @@ struct UpdateArgs {
   const double *jk_norms;
 };
 hipError_t update_launch(const UpdateArgs &a, int rmax_needed, hipStream_t st);
+// deterministic reduction of the MTTKRP split partials into the multi-factor of the mode
+hipError_t reduce_partials_launch(const double *partial, int T, int ldPart, int I, int R,
+                                  double *factor, hipStream_t st);
+// desc: n x {slot, col, rank, jk_mode, jk_fiber}
+hipError_t init_slots_launch(const int *desc, int n, const ModelTable &mt, hipStream_t st);
 
 // Gramians of all modes for freshly admitted models (MultiKtensor::add, multi_ktensor.cpp:88-94)
 struct GramInitArgs {

@@ -1,4 +1,5 @@
-// Batched per-model kernels of the CALS sweep on gfx950: one wavefront per in-flight model.
+// Batched per-model kernels of the CALS sweep on gfx950: one workgroup (4 wavefronts) per
+// in-flight model for the update, one wavefront for the smaller kernels.
 //
 //   update_kernel   src/cals.cpp:239-256 for one mode, all models at once:
 //                   sum of the MTTKRP split partials (fixed order) -> hadamard_but_one
@@ -64,20 +65,66 @@ __device__ __forceinline__ void gramian_wave(const double *panel, int rows, long
   }
 }
 
+// Partial Gramian of rows [row0, row1) on the matrix cores (see gramian_wave); accumulators out.
+__device__ __forceinline__ void gramian_rows(const double *panel, int row0, int row1, int rows,
+                                             long long ld, int r, int lane, v4d &a00, v4d &a01,
+                                             v4d &a11) {
+  const int krow = lane >> 4, lcol = lane & 15;
+  const bool two = r > 16;
+  const bool c0ok = lcol < r, c1ok = (16 + lcol) < r;
+  for (int i0 = row0; i0 < row1; i0 += 8) {
+    const int ia = i0 + krow, ib = i0 + 4 + krow;
+    const bool ra = ia < row1 && ia < rows, rb = ib < row1 && ib < rows;
+    const double p0a = (ra && c0ok) ? panel[ia + ld * lcol] : 0.0;
+    const double p0b = (rb && c0ok) ? panel[ib + ld * lcol] : 0.0;
+    double p1a = 0.0, p1b = 0.0;
+    if (two) {
+      p1a = (ra && c1ok) ? panel[ia + ld * (16 + lcol)] : 0.0;
+      p1b = (rb && c1ok) ? panel[ib + ld * (16 + lcol)] : 0.0;
+    }
+    a00 = __builtin_amdgcn_mfma_f64_16x16x4f64(p0a, p0a, a00, 0, 0, 0);
+    if (two) {
+      a01 = __builtin_amdgcn_mfma_f64_16x16x4f64(p0a, p1a, a01, 0, 0, 0);
+      a11 = __builtin_amdgcn_mfma_f64_16x16x4f64(p1a, p1a, a11, 0, 0, 0);
+    }
+    a00 = __builtin_amdgcn_mfma_f64_16x16x4f64(p0b, p0b, a00, 0, 0, 0);
+    if (two) {
+      a01 = __builtin_amdgcn_mfma_f64_16x16x4f64(p0b, p1b, a01, 0, 0, 0);
+      a11 = __builtin_amdgcn_mfma_f64_16x16x4f64(p1b, p1b, a11, 0, 0, 0);
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
-// update
+// update: one workgroup of 4 waves per model
 // ---------------------------------------------------------------------------------------------
+#define UPD_THREADS 256
+#define UPD_WAVES 4
+
+struct UpdShared {
+  double Hs[CALS_RMAX * CALS_RMAX];
+  double dinv[CALS_RMAX];
+  double lams[CALS_RMAX];
+  double red[UPD_WAVES][CALS_RMAX][2];
+  int redi[UPD_WAVES][CALS_RMAX];
+  double redt[UPD_WAVES];
+  double gp[UPD_WAVES][3][256];
+};
+
+// noinline: inlining all rank classes into one kernel made the register allocator spill heavily
+// (each body alone fits); as separate functions each gets its own allocation.
 template <int RMAX>
-__device__ __forceinline__ void update_body(const UpdateArgs &a, int slot, int r, double *Hs,
-                                            double *dinv, double *lams) {
-  const int lane = threadIdx.x;
+__device__ __attribute__((noinline)) void update_body(const UpdateArgs &a, int slot, int r,
+                                                      UpdShared &sh) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int col = a.mt.col[slot];
   const long long iters = a.mt.iters[slot];
   const int jkf = (a.mt.jk_mode[slot] == a.mode) ? a.mt.jk_fiber[slot] : -1;
   const int I = a.I;
+  double *Hs = sh.Hs;
 
   // H = hadamard of the other modes' Gramians (hadamard_but_one)
-  for (int e = lane; e < r * r; e += 64) {
+  for (int e = tid; e < r * r; e += UPD_THREADS) {
     const int i = e % r, j = e / r;
     double h = 1.0;
     for (int m = 0; m < a.n_modes; ++m)
@@ -86,15 +133,16 @@ __device__ __forceinline__ void update_body(const UpdateArgs &a, int slot, int r
   }
   __syncthreads();
 
-  // dpotrf('L') restated as unblocked dpotf2 (lane = row).  info != 0: stop, keep going with
-  // whatever is in H, as the reference does (update.cpp:183-185 only logs).
+  // dpotrf('L') restated as unblocked dpotf2 (lane = row; every wave computes, wave 0 writes).
+  // info != 0: stop, keep going with whatever is in H, as the reference does
+  // (update.cpp:183-185 only logs).
   int info = 0;
   for (int j = 0; j < r; ++j) {
     double ajj = Hs[j + RMAX * j];
     for (int k = 0; k < j; ++k) ajj -= Hs[j + RMAX * k] * Hs[j + RMAX * k];
     if (!(ajj > 0.0)) {
       __syncthreads();
-      if (lane == 0) Hs[j + RMAX * j] = ajj;
+      if (tid == 0) Hs[j + RMAX * j] = ajj;
       info = j + 1;
       break;
     }
@@ -106,41 +154,46 @@ __device__ __forceinline__ void update_body(const UpdateArgs &a, int slot, int r
       s = s / ajj;
     }
     __syncthreads();
-    if (lane == j)
-      Hs[j + RMAX * j] = ajj;
-    else if (lane > j && lane < r)
-      Hs[lane + RMAX * j] = s;
+    if (wave == 0) {
+      if (lane == j)
+        Hs[j + RMAX * j] = ajj;
+      else if (lane > j && lane < r)
+        Hs[lane + RMAX * j] = s;
+    }
     __syncthreads();
   }
   __syncthreads();
-  if (lane < r) dinv[lane] = 1.0 / Hs[lane + RMAX * lane];
-  if (lane == 0) a.mt.potrf_info[slot] = info;
+  if (tid < r) sh.dinv[tid] = 1.0 / Hs[tid + RMAX * tid];
+  if (tid == 0) a.mt.potrf_info[slot] = info;
   __syncthreads();
+  const double *dinv = sh.dinv;
 
   double *fac = a.factor + (long long)I * col;
-  const long long tile = (long long)a.ldPart * CALS_BN;
   const bool first = (iters == 1);
 
+  // per-column statistics of this thread's rows: first sweep: st1 = sum of squares; later:
+  // st1 = max|x|, st2 = x there, sti = its row (cblas_idamax: first index of the largest |x|)
+  double st1[RMAX], st2[RMAX];
+  int sti[RMAX];
+#pragma unroll
+  for (int c = 0; c < RMAX; ++c) {
+    st1[c] = first ? 0.0 : -1.0;
+    st2[c] = 0.0;
+    sti[c] = 0x7fffffff;
+  }
   double t3 = 0.0;
 
-  // pass 1, one row per lane: G row -> two triangular solves -> unnormalised factor row
-  for (int i = lane; i < I; i += 64) {
+  // pass 1, one row per thread: G row -> two triangular solves -> unnormalised factor row
+  for (int i = tid; i < I; i += UPD_THREADS) {
     double x[RMAX], g[RMAX];
     // L stays in LDS (broadcast reads): without this barrier LICM hoists all r^2/2 entries of L
     // out of the row loop into VGPRs and the kernel spills.
     asm volatile("" ::: "memory");
-    // G row = sum over the T team partials, fixed order
+    // G row: the MTTKRP result, already reduced over the split partials into the factor buffer
+    // (the reference's MTTKRP overwrites factor n too, src/utils/mttkrp.cpp:311)
 #pragma unroll
     for (int c = 0; c < RMAX; ++c) {
-      x[c] = 0.0;
-      if (c < r) {
-        const int cg = col + c;
-        const double *p = a.partial + (long long)(cg >> 7) * a.T * tile + i +
-                          (long long)a.ldPart * (cg & (CALS_BN - 1));
-        double s = 0.0;
-        for (int t = 0; t < a.T; ++t) s += p[t * tile];
-        x[c] = s;
-      }
+      x[c] = (c < r) ? fac[i + (long long)I * c] : 0.0;
       g[c] = x[c];
     }
     // B := B * inv(L^T)   (dtrsm Right, Lower, Trans)
@@ -172,68 +225,144 @@ __device__ __forceinline__ void update_body(const UpdateArgs &a, int slot, int r
       if (c < r) {
         fac[i + (long long)I * c] = x[c];
         t3 += x[c] * g[c];  // = lambda_c * A[i,c] * G[i,c] of compute_fast_error's term3
+        if (first) {
+          st1[c] += x[c] * x[c];
+        } else {
+          const double ax = fabs(x[c]);
+          if (ax > st1[c]) {
+            st1[c] = ax;
+            st2[c] = x[c];
+            sti[c] = i;
+          }
+        }
+      }
+    }
+  }
+
+  // column scales: wave butterflies (independent per column, so they pipeline), then the four
+  // waves are combined in fixed order by thread c
+#pragma unroll
+  for (int c = 0; c < RMAX; ++c) {
+    if (c < r) {
+      if (first) {
+        const double tot = wave_sum(st1[c]);
+        if (lane == 0) sh.red[wave][c][0] = tot;
+      } else {
+        double m = st1[c], v = st2[c];
+        int ix = sti[c];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+          const double m2 = __shfl_xor(m, off);
+          const double v2 = __shfl_xor(v, off);
+          const int i2 = __shfl_xor(ix, off);
+          const bool take = (m2 > m) || (m2 == m && i2 < ix);
+          m = take ? m2 : m;
+          v = take ? v2 : v;
+          ix = take ? i2 : ix;
+        }
+        if (lane == 0) {
+          sh.red[wave][c][0] = m;
+          sh.red[wave][c][1] = v;
+          sh.redi[wave][c] = ix;
+        }
       }
     }
   }
   t3 = wave_sum(t3);
+  if (lane == 0) sh.redt[wave] = t3;
   __syncthreads();
-
-  // pass 2, one column at a time: scale = 2-norm on a model's first sweep, signed max-abs entry
-  // (cblas_idamax: first index of the largest |x|) afterwards; cblas_dscal by 1/lambda unless 0
-  for (int c = 0; c < r; ++c) {
-    double *fc = fac + (long long)I * c;
+  if (tid < r) {
     double lam;
     if (first) {
-      double ss = 0.0;
-      for (int i = lane; i < I; i += 64) ss += fc[i] * fc[i];
-      lam = sqrt(wave_sum(ss));
+      double tot = 0.0;
+      for (int w = 0; w < UPD_WAVES; ++w) tot += sh.red[w][tid][0];
+      lam = sqrt(tot);
     } else {
-      double m = -1.0, v = 0.0;
-      int ix = 0x7fffffff;
-      for (int i = lane; i < I; i += 64) {
-        const double xv = fc[i], ax = fabs(xv);
-        if (ax > m) {
-          m = ax;
-          v = xv;
-          ix = i;
+      double m = sh.red[0][tid][0], v = sh.red[0][tid][1];
+      int ix = sh.redi[0][tid];
+      for (int w = 1; w < UPD_WAVES; ++w) {
+        const double m2 = sh.red[w][tid][0];
+        const int i2 = sh.redi[w][tid];
+        if ((m2 > m) || (m2 == m && i2 < ix)) {
+          m = m2;
+          v = sh.red[w][tid][1];
+          ix = i2;
         }
-      }
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) {
-        const double m2 = __shfl_xor(m, off);
-        const double v2 = __shfl_xor(v, off);
-        const int i2 = __shfl_xor(ix, off);
-        const bool take = (m2 > m) || (m2 == m && i2 < ix);
-        m = take ? m2 : m;
-        v = take ? v2 : v;
-        ix = take ? i2 : ix;
       }
       lam = v;
     }
-    if (lane == 0) {
-      lams[c] = lam;
-      a.lambda[col + c] = lam;
-    }
-    if (lam != 0.0) {
-      const double sc = 1.0 / lam;
-      for (int i = lane; i < I; i += 64) fc[i] = sc * fc[i];
+    sh.lams[tid] = lam;
+    a.lambda[col + tid] = lam;
+  }
+  __syncthreads();
+  t3 = sh.redt[0] + sh.redt[1] + sh.redt[2] + sh.redt[3];
+  const double *lams = sh.lams;
+
+  // pass 2: cblas_dscal by 1/lambda (skipped for lambda == 0); each thread rescales its own rows
+  for (int i = tid; i < I; i += UPD_THREADS) {
+#pragma unroll
+    for (int c = 0; c < RMAX; ++c) {
+      if (c < r) {
+        const double lam = lams[c];
+        if (lam != 0.0) fac[i + (long long)I * c] = (1.0 / lam) * fac[i + (long long)I * c];
+      }
     }
   }
   __syncthreads();
 
-  gramian_wave(fac, I, I, r, a.gram[a.mode] + CALS_RMAX * (long long)col, lane);
+  // update_gramian: rows split over the four waves, partial tiles combined in fixed order
+  {
+    v4d a00 = {0.0, 0.0, 0.0, 0.0}, a01 = {0.0, 0.0, 0.0, 0.0}, a11 = {0.0, 0.0, 0.0, 0.0};
+    const int chunk = ((I + UPD_WAVES - 1) / UPD_WAVES + 7) / 8 * 8;
+    const int row0 = wave * chunk, row1 = min(I, row0 + chunk);
+    gramian_rows(fac, row0, row1, I, I, r, lane, a00, a01, a11);
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      sh.gp[wave][0][lane * 4 + reg] = a00[reg];
+      sh.gp[wave][1][lane * 4 + reg] = a01[reg];
+      sh.gp[wave][2][lane * 4 + reg] = a11[reg];
+    }
+  }
+  __syncthreads();
+  {
+    double *g = a.gram[a.mode] + CALS_RMAX * (long long)col;
+    const int tile = tid >> 6;  // 0: (0,0)  1: (0,1)+(1,0)  2: (1,1); wave 3 idles
+    if (tile < 3) {
+      const int krow = lane >> 4, lcol = lane & 15;
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int e = lane * 4 + reg;
+        const double v = ((sh.gp[0][tile][e] + sh.gp[1][tile][e]) + sh.gp[2][tile][e]) + sh.gp[3][tile][e];
+        const int row = krow + 4 * reg;  // f64 C/D layout: D[row = krow + 4*reg][col = lcol]
+        if (tile == 0) {
+          if (row < r && lcol < r) g[row + CALS_RMAX * lcol] = v;
+        } else if (tile == 1) {
+          if (row < r && 16 + lcol < r) {
+            g[row + CALS_RMAX * (16 + lcol)] = v;
+            g[(16 + lcol) + CALS_RMAX * row] = v;
+          }
+        } else {
+          if (16 + row < r && 16 + lcol < r) g[(16 + row) + CALS_RMAX * (16 + lcol)] = v;
+        }
+      }
+    }
+  }
 
   if (a.is_last) {
     __syncthreads();
     double t2 = 0.0;
-    for (int e = lane; e < r * r; e += 64) {
+    for (int e = tid; e < r * r; e += UPD_THREADS) {
       const int i = e % r, j = e / r;
       double h = 1.0;
       for (int m = 0; m < a.n_modes; ++m) h *= a.gram[m][i + CALS_RMAX * (long long)(col + j)];
       t2 += lams[i] * lams[j] * h;
     }
     t2 = wave_sum(t2);
-    if (lane == 0) {
+    __syncthreads();
+    if (lane == 0) sh.redt[wave] = t2;
+    __syncthreads();
+    if (tid == 0) {
+      t2 = sh.redt[0] + sh.redt[1] + sh.redt[2] + sh.redt[3];
       const int jm = a.mt.jk_mode[slot];
       const double xn = (jm >= 0) ? a.jk_norms[a.mt.jk_fiber[slot]] : a.X_norm;
       const double e2 = fmax(xn * xn + t2 - 2.0 * t3, 0.0);
@@ -246,31 +375,86 @@ __device__ __forceinline__ void update_body(const UpdateArgs &a, int slot, int r
   }
 }
 
-__global__ void __launch_bounds__(64) update_kernel(const UpdateArgs a) {
-  __shared__ double Hs[CALS_RMAX * CALS_RMAX];
-  __shared__ double dinv[CALS_RMAX];
-  __shared__ double lams[CALS_RMAX];
+__global__ void __launch_bounds__(UPD_THREADS, 1) update_kernel(const UpdateArgs a) {
+  __shared__ UpdShared sh;
   const int slot = a.slots[blockIdx.x];
   const int r = a.mt.rank[slot];
   if (r <= 4)
-    update_body<4>(a, slot, r, Hs, dinv, lams);
+    update_body<4>(a, slot, r, sh);
   else if (r <= 8)
-    update_body<8>(a, slot, r, Hs, dinv, lams);
+    update_body<8>(a, slot, r, sh);
   else if (r <= 12)
-    update_body<12>(a, slot, r, Hs, dinv, lams);
+    update_body<12>(a, slot, r, sh);
   else if (r <= 16)
-    update_body<16>(a, slot, r, Hs, dinv, lams);
+    update_body<16>(a, slot, r, sh);
   else if (r <= 20)
-    update_body<20>(a, slot, r, Hs, dinv, lams);
+    update_body<20>(a, slot, r, sh);
   else if (r <= 24)
-    update_body<24>(a, slot, r, Hs, dinv, lams);
+    update_body<24>(a, slot, r, sh);
   else
-    update_body<32>(a, slot, r, Hs, dinv, lams);
+    update_body<32>(a, slot, r, sh);
+}
+
+// G[i, c] = sum_t partial[(c / 128) * T + t][i, c % 128], t = 0..T-1 in this fixed order
+// (deterministic split-K reduction of the MTTKRP), written into the multi-factor of the mode.
+__global__ void __launch_bounds__(256) reduce_partials_kernel(const double *partial, int T,
+                                                              int ldPart, int I, double *factor) {
+  const int c = blockIdx.y;
+  const long long tile = (long long)ldPart * CALS_BN;
+  const double *base = partial + (long long)(c >> 7) * T * tile + (long long)ldPart * (c & (CALS_BN - 1));
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < I; i += gridDim.x * blockDim.x) {
+    const double *p = base + i;
+    double s = 0.0;
+    int t = 0;
+    for (; t + 4 <= T; t += 4) {
+      const double v0 = p[(t + 0) * tile], v1 = p[(t + 1) * tile], v2 = p[(t + 2) * tile],
+                   v3 = p[(t + 3) * tile];
+      s += v0;
+      s += v1;
+      s += v2;
+      s += v3;
+    }
+    for (; t < T; ++t) s += p[t * tile];
+    factor[i + (long long)I * c] = s;
+  }
+}
+
+hipError_t reduce_partials_launch(const double *partial, int T, int ldPart, int I, int R,
+                                  double *factor, hipStream_t st) {
+  if (R <= 0) return hipSuccess;
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((I + 255) / 256, R), dim3(256), 0, st, partial, T,
+                     ldPart, I, factor);
+  return hipGetLastError();
+}
+
+// per-slot scalars of freshly admitted models (MultiKtensor::add: iters = 1, fresh LS state)
+__global__ void init_slots_kernel(const int *desc, int n, ModelTable mt) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const int slot = desc[5 * k];
+  mt.col[slot] = desc[5 * k + 1];
+  mt.rank[slot] = desc[5 * k + 2];
+  mt.jk_mode[slot] = desc[5 * k + 3];
+  mt.jk_fiber[slot] = desc[5 * k + 4];
+  mt.iters[slot] = 1;
+  mt.err[slot] = 0.0;
+  mt.fit[slot] = 0.0;
+  mt.old_fit[slot] = 0.0;
+  mt.potrf_info[slot] = 0;
+  mt.ls_iter[slot] = 0;
+  mt.ls_updated_last[slot] = 0;
+  mt.flags[slot] = 0;
+}
+
+hipError_t init_slots_launch(const int *desc, int n, const ModelTable &mt, hipStream_t st) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(init_slots_kernel, dim3((n + 127) / 128), dim3(128), 0, st, desc, n, mt);
+  return hipGetLastError();
 }
 
 hipError_t update_launch(const UpdateArgs &a, int, hipStream_t st) {
   if (a.n_slots <= 0) return hipSuccess;
-  hipLaunchKernelGGL(update_kernel, dim3(a.n_slots), dim3(64), 0, st, a);
+  hipLaunchKernelGGL(update_kernel, dim3(a.n_slots), dim3(UPD_THREADS), 0, st, a);
   return hipGetLastError();
 }
 

@@ -24,6 +24,8 @@
 // the A-operand ds_read_b64 of lanes (l&15, l>>4) is bank-conflict free.
 #include "cals_hip_internal.h"
 
+#include <cstdlib>
+
 namespace calship {
 
 typedef double v4d __attribute__((ext_vector_type(4)));
@@ -43,7 +45,11 @@ struct MtCfg {
 #define GLOBAL_AS __attribute__((address_space(1)))
 #define LDS_AS __attribute__((address_space(3)))
 
-template <int MT>
+// VAR (tuning variants, selected with CALS_MTTKRP_VARIANT):
+//   bit 0: A-operand reads are unmerged ds_read_b64 software-pipelined PF MFMAs ahead
+//   bit 1: the next stage's LDS-DMA is issued after the first MFMA block of the current stage
+//          instead of before it
+template <int MT, int VAR>
 __global__ void __launch_bounds__(512, 2) mttkrp_kernel(const MttkrpArgs a) {
   typedef MtCfg<MT> C;
   extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -171,8 +177,9 @@ __global__ void __launch_bounds__(512, 2) mttkrp_kernel(const MttkrpArgs a) {
       }
       ab_loaded = ab_c;
     }
-    if (un < u_end) {
-      stage_of(un, ab_n, s_n, n_n);
+    const bool have_next = un < u_end;
+    if (have_next) stage_of(un, ab_n, s_n, n_n);
+    if (!(VAR & 2) && have_next) {
       issue_stage(buf ^ 1, ab_n, s_n, n_n);
       issue_q(buf ^ 1, s_n, n_n);
     }
@@ -183,13 +190,45 @@ __global__ void __launch_bounds__(512, 2) mttkrp_kernel(const MttkrpArgs a) {
     for (int j = 0; j < n_c; ++j) {
       const double q0 = qlds[buf * C::QSTAGE + j * CALS_BN + wave * 16 + lcol];
       const double *sl = abase + buf * C::STAGE + j * C::SLAB;
+      if (VAR & 1) {
+        double bq[4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const double bq = preg[q] * q0;
+        for (int q = 0; q < 4; ++q) bq[q] = preg[q] * q0;
+        // volatile LDS pointer: no ds_read2 merging, reads stay in program order
+        const volatile LDS_AS double *vsl = (const volatile LDS_AS double *)sl;
 #pragma unroll
-        for (int t = 0; t < MT; ++t) {
-          const double av = sl[(4 * q) * C::LDL + 16 * t];
-          acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bq, acc[t], 0, 0, 0);
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+          for (int t = 0; t < MT; ++t) {
+            const double av = vsl[(4 * q) * C::LDL + 16 * t];
+            acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bq[q], acc[t], 0, 0, 0);
+          }
+          if ((VAR & 2) && q == 0 && j == 0 && have_next) {
+            issue_stage(buf ^ 1, ab_n, s_n, n_n);
+            issue_q(buf ^ 1, s_n, n_n);
+          }
+        }
+        constexpr int PF = 4;
+        __builtin_amdgcn_sched_group_barrier(0x100, PF, 0);
+#pragma unroll
+        for (int i = 0; i < 4 * MT - PF; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, PF, 0);
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const double bq = preg[q] * q0;
+#pragma unroll
+          for (int t = 0; t < MT; ++t) {
+            const double av = sl[(4 * q) * C::LDL + 16 * t];
+            acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bq, acc[t], 0, 0, 0);
+          }
+          if ((VAR & 2) && q == 0 && j == 0 && have_next) {
+            issue_stage(buf ^ 1, ab_n, s_n, n_n);
+            issue_q(buf ^ 1, s_n, n_n);
+          }
         }
       }
     }
@@ -226,19 +265,38 @@ int mttkrp_pick_mt(int m_tiles) {
   return 0;
 }
 
-template <int MT>
-static hipError_t launch_mt(int m_blocks, const MttkrpArgs &a, hipStream_t st) {
+template <int MT, int VAR>
+static hipError_t launch_mt_var(int m_blocks, const MttkrpArgs &a, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&mttkrp_kernel<MT>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&mttkrp_kernel<MT, VAR>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize,
                                        MtCfg<MT>::LDS_BYTES);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
   dim3 grid(a.grid, m_blocks, 1), block(512, 1, 1);
-  hipLaunchKernelGGL(mttkrp_kernel<MT>, grid, block, MtCfg<MT>::LDS_BYTES, st, a);
+  hipLaunchKernelGGL((mttkrp_kernel<MT, VAR>), grid, block, MtCfg<MT>::LDS_BYTES, st, a);
   return hipGetLastError();
+}
+
+static int mttkrp_variant() {
+  static int v = -1;
+  if (v < 0) {
+    const char *s = getenv("CALS_MTTKRP_VARIANT");
+    v = s ? atoi(s) & 3 : 3;
+  }
+  return v;
+}
+
+template <int MT>
+static hipError_t launch_mt(int m_blocks, const MttkrpArgs &a, hipStream_t st) {
+  switch (mttkrp_variant()) {
+    case 1: return launch_mt_var<MT, 1>(m_blocks, a, st);
+    case 2: return launch_mt_var<MT, 2>(m_blocks, a, st);
+    case 3: return launch_mt_var<MT, 3>(m_blocks, a, st);
+    default: return launch_mt_var<MT, 0>(m_blocks, a, st);
+  }
 }
 
 size_t mttkrp_lds_bytes(int MT) {
