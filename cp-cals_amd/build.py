@@ -36,6 +36,15 @@ def build(force=False, verbose=False):
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
+    # C++ host layer (cals::cp_cals & value classes) over the C ABI
+    api_src = os.path.join(HERE, "cals", "cals.cpp")
+    api_lib = os.path.join(HERE, "libcals.so")
+    if force or _newer(api_lib, [api_src, os.path.join(HERE, "cals", "cals.h"), LIB]):
+        cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-fPIC", "-shared", "-o", api_lib, api_src,
+               "-L" + HERE, "-lcals_hip", "-Wl,-rpath,$ORIGIN"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
     return LIB
 
 

@@ -1,0 +1,320 @@
+// C++ host layer over the C ABI (include/cals_hip.h): the value classes and the cp_cals() entry
+// point of HPAC/CP-CALS with the same names, argument meaning and ownership rules, so that a caller
+// written against the reference's headers (include/cals.h, tensor.h, matrix.h, ktensor.h) compiles
+// against this one.  Only what the hot path's callers touch is provided.
+// Everything numeric on the path runs in libcals_hip.so; the small host loops below (fill,
+// normalize, to_tensor ...) are the Ktensor conveniences the callers use around cp_cals.
+#ifndef CALS_AMD_CALS_H
+#define CALS_AMD_CALS_H
+
+#include <cfloat>
+#include <cmath>
+#include <cstddef>
+#include <cstdint>
+#include <functional>
+#include <iostream>
+#include <memory>
+#include <queue>
+#include <random>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+typedef size_t dim_t;  // include/definitions.h:18
+
+namespace cals {
+using std::vector;
+
+namespace update {  // include/utils/update.h:7
+enum UPDATE_METHOD { UNCONSTRAINED = 0, NNLS, LENGTH };
+}
+namespace mttkrp {  // include/utils/mttkrp.h:23-31 (kept for source compatibility; one fused kernel here)
+enum MTTKRP_METHOD { MTTKRP = 0, TWOSTEP0, TWOSTEP1, AUTO, LENGTH };
+}
+namespace ls {  // include/utils/line_search.h:8
+enum LS_METHOD { NO_ERROR_CHECKING = 0, ERROR_CHECKING_SERIAL, ERROR_CHECKING_PARALLEL, LENGTH };
+}
+
+// include/tensor.h: column-major dense tensor, owning buffer or view
+class Tensor {
+ protected:
+  dim_t n_elements{0};
+  vector<dim_t> modes{};
+  std::unique_ptr<double[]> owned{};
+  double *data{nullptr};
+  int rank{0};
+
+ public:
+  Tensor() = default;
+  explicit Tensor(const vector<dim_t> &modes_) : modes(modes_) {
+    n_elements = 1;
+    for (auto m : modes) n_elements *= m;
+    owned.reset(new double[n_elements]);
+    data = owned.get();
+  }
+  Tensor(const vector<dim_t> &modes_, double *view) : modes(modes_), data(view) {  // tensor.cpp:28-33
+    n_elements = 1;
+    for (auto m : modes) n_elements *= m;
+  }
+  Tensor(dim_t rows, dim_t cols, double *view = nullptr) : modes{rows, cols} {
+    n_elements = rows * cols;
+    if (view)
+      data = view;
+    else {
+      owned.reset(new double[n_elements]);
+      data = owned.get();
+    }
+  }
+  Tensor(Tensor &&) = default;
+  Tensor &operator=(Tensor &&) = default;
+  Tensor(const Tensor &rhs) : n_elements(rhs.n_elements), modes(rhs.modes), rank(rhs.rank) {
+    if (rhs.is_view())
+      data = rhs.data;
+    else {
+      owned.reset(new double[n_elements]);
+      data = owned.get();
+      std::copy(rhs.data, rhs.data + n_elements, data);
+    }
+  }
+  Tensor &operator=(const Tensor &rhs) {
+    if (this != &rhs) {
+      Tensor t(rhs);
+      *this = std::move(t);
+    }
+    return *this;
+  }
+  virtual ~Tensor() = default;
+
+  dim_t get_n_elements() const noexcept { return n_elements; }
+  const vector<dim_t> &get_modes() const noexcept { return modes; }
+  dim_t get_n_modes() const noexcept { return modes.size(); }
+  double *get_data() const noexcept { return data; }
+  int get_rank() const noexcept { return rank; }
+  void set_rank(int r) noexcept { rank = r; }
+  bool is_view() const noexcept { return owned == nullptr && data != nullptr; }
+  double &operator[](dim_t i) noexcept { return data[i]; }
+  double operator[](dim_t i) const noexcept { return data[i]; }
+  double norm() const {  // include/tensor.h:196
+    double s = 0.0;
+    for (dim_t i = 0; i < n_elements; i++) s += data[i] * data[i];
+    return std::sqrt(s);
+  }
+  Tensor &fill(const std::function<double()> &&gen) {  // tensor.cpp:137-141
+    for (dim_t i = 0; i < n_elements; i++) data[i] = gen();
+    return *this;
+  }
+  Tensor &zero() {
+    for (dim_t i = 0; i < n_elements; i++) data[i] = 0.0;
+    return *this;
+  }
+  Tensor &randomize() {  // tensor.cpp:122-130
+    std::uniform_real_distribution<double> dist(-1.0, 1.0);
+    std::random_device device;
+    std::mt19937 generator(device());
+    return fill([&]() { return dist(generator); });
+  }
+  Tensor &copy(const Tensor &rhs) {
+    std::copy(rhs.data, rhs.data + n_elements, data);
+    return *this;
+  }
+};
+
+// include/matrix.h
+class Matrix : public Tensor {
+  dim_t rows{0}, cols{0}, col_stride{0};
+
+ public:
+  Matrix() = default;
+  Matrix(dim_t r, dim_t c) : Tensor(r, c), rows(r), cols(c), col_stride(r) {}
+  Matrix(dim_t r, dim_t c, double *view) : Tensor(r, c, view), rows(r), cols(c), col_stride(r) {}
+  dim_t get_rows() const noexcept { return rows; }
+  dim_t get_cols() const noexcept { return cols; }
+  dim_t get_col_stride() const noexcept { return col_stride; }
+  double &operator()(dim_t r, dim_t c) noexcept { return data[r + c * col_stride]; }
+  double operator()(dim_t r, dim_t c) const noexcept { return data[r + c * col_stride]; }
+};
+
+// include/ktensor.h
+class Ktensor {
+  int id{-1};
+  dim_t components{0}, iters{0};
+  double fit{0.0}, old_fit{0.0}, approx_error{0.0};
+  bool normalized{false};
+  struct { bool enabled{false}; dim_t fiber{0}; dim_t mode{0}; } jk;
+  vector<dim_t> modes{};
+  vector<double> lambda{};
+  vector<Matrix> factors{};
+  static int &next_id() { static int v = 1; return v; }
+
+ public:
+  Ktensor() = default;
+  Ktensor(dim_t components_, const vector<dim_t> &modes_)
+      : id(next_id()++), components(components_), modes(modes_), lambda(components_, 0.0) {
+    for (auto m : modes) factors.emplace_back(m, components);
+  }
+  Ktensor(dim_t components_, const vector<dim_t> &modes_, dim_t jk_fiber, dim_t jk_mode = 0)
+      : Ktensor(components_, modes_) {
+    jk.enabled = true;
+    jk.fiber = jk_fiber;
+    jk.mode = jk_mode;
+  }
+  Ktensor(Ktensor &&) = default;
+  Ktensor &operator=(Ktensor &&) = default;
+  Ktensor(const Ktensor &rhs)  // a copy gets a fresh id (include/ktensor.h:95-110)
+      : id(next_id()++), components(rhs.components), jk(rhs.jk), modes(rhs.modes), lambda(rhs.lambda),
+        factors(rhs.factors) {}
+  Ktensor &operator=(const Ktensor &rhs) {
+    if (this != &rhs) {
+      id = next_id()++;
+      components = rhs.components;
+      lambda = rhs.lambda;
+      jk = rhs.jk;
+      modes = rhs.modes;
+      factors = rhs.factors;
+    }
+    return *this;
+  }
+
+  dim_t get_components() const noexcept { return components; }
+  dim_t get_iters() const noexcept { return iters; }
+  int get_id() const noexcept { return id; }
+  bool is_jk() const noexcept { return jk.enabled; }
+  dim_t get_jk_mode() const noexcept { return jk.mode; }
+  dim_t get_jk_fiber() const noexcept { return jk.fiber; }
+  double get_approximation_error() const noexcept { return approx_error; }
+  double get_fit() const noexcept { return fit; }
+  const vector<dim_t> &get_modes() const noexcept { return modes; }
+  dim_t get_n_modes() const noexcept { return factors.size(); }
+  vector<Matrix> &get_factors() noexcept { return factors; }
+  const vector<Matrix> &get_factors() const noexcept { return factors; }
+  Matrix &get_factor(dim_t m) noexcept { return factors.at(m); }
+  const Matrix &get_factor(dim_t m) const noexcept { return factors.at(m); }
+  const Matrix &get_last_factor() const noexcept { return factors.back(); }
+  vector<double> &get_lambda() noexcept { return lambda; }
+  const vector<double> &get_lambda() const noexcept { return lambda; }
+  void set_iters(dim_t v) noexcept { iters = v; }
+  void set_approximation_error(double v) noexcept { approx_error = v; }
+  void set_fit(double f, double of) noexcept { fit = f; old_fit = of; }
+  double calculate_new_fit(double X_norm) noexcept {  // include/ktensor.h:178-183
+    old_fit = fit;
+    fit = 1 - std::fabs(approx_error) / X_norm;
+    return fit;
+  }
+  double get_fit_diff() const noexcept { return std::fabs(old_fit - fit); }
+
+  Ktensor &normalize() {  // ktensor.cpp:85-99
+    for (auto &l : lambda) l = 1.0;
+    for (auto &f : factors)
+      for (dim_t c = 0; c < components; c++) {
+        double s = 0.0;
+        for (dim_t i = 0; i < f.get_rows(); i++) s += f(i, c) * f(i, c);
+        const double coeff = std::sqrt(s), inv = 1 / coeff;
+        for (dim_t i = 0; i < f.get_rows(); i++) f(i, c) *= inv;
+        lambda[c] *= coeff;
+      }
+    normalized = true;
+    return *this;
+  }
+  Ktensor &denormalize() {  // ktensor.cpp:101-107
+    auto &f = factors[0];
+    for (dim_t c = 0; c < components; c++)
+      for (dim_t i = 0; i < f.get_rows(); i++) f(i, c) *= lambda[c];
+    normalized = false;
+    return *this;
+  }
+  void set_jk_fiber(double value) noexcept {  // include/ktensor.h:316-325
+    if (!jk.enabled) return;
+    auto &f = factors[jk.mode];
+    for (dim_t c = 0; c < components; c++)
+      f(jk.fiber, c) = std::isnan(value) ? NAN : f(jk.fiber, c) * value;
+  }
+  Ktensor &fill(std::function<double()> &&func) {  // ktensor.cpp:21-30
+    for (auto &f : factors) f.fill(std::forward<decltype(func)>(func));
+    if (jk.enabled) set_jk_fiber(0.0);
+    return normalize();
+  }
+  Ktensor &randomize() {  // ktensor.cpp:11-19
+    for (auto &f : factors) f.randomize();
+    if (jk.enabled) set_jk_fiber(0.0);
+    return normalize();
+  }
+  Ktensor &to_jk(dim_t mode, dim_t fiber) {
+    jk.enabled = true;
+    jk.mode = mode;
+    jk.fiber = fiber;
+    return *this;
+  }
+  Tensor to_tensor() const {  // ktensor.cpp:32-64
+    Tensor X(modes);
+    vector<dim_t> idx(modes.size(), 0);
+    for (dim_t e = 0; e < X.get_n_elements(); e++) {
+      double s = 0.0;
+      for (dim_t r = 0; r < components; r++) {
+        double m = 1.0;
+        for (dim_t f = 0; f < factors.size(); f++) m *= factors[f](idx[f], r);
+        s += lambda[r] * m;
+      }
+      X[e] = s;
+      for (dim_t n = 0; n < modes.size(); n++) {
+        if (++idx[n] < modes[n]) break;
+        idx[n] = 0;
+      }
+    }
+    return X;
+  }
+};
+
+typedef std::queue<std::reference_wrapper<Ktensor>> KtensorQueue;  // include/cals.h:22
+
+// include/cals.h:27-63 (timer matrices are not produced: hipEvent statistics are available
+// through cals_hip_get_kernel_stats instead)
+struct CalsReport {
+  int tensor_rank{0};
+  dim_t n_modes{0};
+  vector<dim_t> modes{};
+  double X_norm{0.0};
+  dim_t iter{0};
+  dim_t max_iter{0};
+  int n_threads{1};
+  dim_t buffer_size{0};
+  int n_ktensors{0};
+  int ktensor_comp_sum{0};
+  double tol{0.0};
+  bool cuda{true};
+  update::UPDATE_METHOD update_method{update::UNCONSTRAINED};
+  std::string output_file_name{};
+  bool line_search{false};
+  int line_search_interval{0};
+  double line_search_step{0.0};
+  dim_t ls_performed{0};
+  dim_t ls_failed{0};
+  ls::LS_METHOD line_search_method{ls::NO_ERROR_CHECKING};
+  double total_time{0.0};
+};
+
+// include/cals.h:138-159.  `cuda` selects the device path in the reference; this library HAS only
+// the device path (MI355X), so it defaults to true and cp_cals throws if it is false.
+struct CalsParams {
+  update::UPDATE_METHOD update_method{update::UNCONSTRAINED};
+  mttkrp::MTTKRP_METHOD mttkrp_method{mttkrp::AUTO};
+  dim_t max_iterations{200};
+  double tol{1e-7};
+  bool cuda{true};
+  dim_t buffer_size{4200};
+  bool line_search{false};
+  int line_search_interval{5};
+  double line_search_step{0};
+  ls::LS_METHOD line_search_method{ls::NO_ERROR_CHECKING};
+  bool force_max_iter{false};
+  bool always_evict_first{false};
+  int device{0};  // added: HIP device ordinal (default preserves single-GPU behaviour)
+  void print() const;
+};
+
+// Fits every Ktensor of the queue to X with concurrent ALS on the GPU and overwrites it with the
+// result (factors, lambda, error, fit, iters); the queue is empty on return (include/cals.h:183-196).
+// Throws std::runtime_error on any engine error (the reference exit()s on device errors).
+CalsReport cp_cals(const Tensor &X, KtensorQueue &kt_queue, CalsParams &cals_params);
+
+}  // namespace cals
+#endif

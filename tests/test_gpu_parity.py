@@ -228,6 +228,18 @@ def test_rejects_bad_input_loudly(cc, inputs):
     e.close()
 
 
+@pytest.mark.parametrize("arg", ["", "ls"])
+def test_cpp_api_cp_cals(arg):
+    """cals::cp_cals (C++ mirror of the reference boundary) == oracle, restated SimpleCorrectness /
+    LineSearchCorrectness; the binary is built by __graft_entry__.build()."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "cpp", "test_cals_api")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    r = subprocess.run([exe] + ([arg] if arg else []), capture_output=True, text=True, timeout=300)
+    print(r.stdout, r.stderr)
+    assert r.returncode == 0, r.stdout + r.stderr
+
+
 # ---- full-size properties (BASELINE configs 2 and 3): no oracle run, exact identities instead ----
 def test_full_size_c3_mttkrp_identities(cc, inputs):
     """300^3 fp64, 256 models ranks 1..20 (R = 2656): (1) columns of a model that is all-ones give
