@@ -63,7 +63,7 @@ EXPORTS = [
     "cals_hip_debug_get_lambda", "cals_hip_debug_get_gramian", "cals_hip_debug_model_status",
     "cals_hip_debug_get_norms", "cals_hip_set_profiling", "cals_hip_get_kernel_stats",
     "cals_hip_reset_kernel_stats", "cals_hip_stream", "cals_hip_device_count",
-    "cals_hip_host_first_fit", "cals_hip_host_compress_plan", "cals_hip_host_active_cols",
+    "cals_hip_debug_clock", "cals_hip_host_first_fit", "cals_hip_host_compress_plan", "cals_hip_host_active_cols",
 ]
 
 _LIB = None
@@ -107,6 +107,7 @@ def load_library():
     lib.cals_hip_stream.argtypes = [vp]
     lib.cals_hip_stream.restype = vp
     lib.cals_hip_device_count.restype = C.c_int
+    lib.cals_hip_debug_clock.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     pi64 = C.POINTER(i64)
     lib.cals_hip_host_first_fit.argtypes = [pi64, i64, i64]
     lib.cals_hip_host_first_fit.restype = i64
@@ -296,6 +297,11 @@ class Engine:
 
     def reset_kernel_stats(self):
         self._chk(self.lib.cals_hip_reset_kernel_stats(self.h))
+
+    def debug_clock(self, n_workgroups=252):
+        cyc, ghz = C.c_double(0), C.c_double(0)
+        self._chk(self.lib.cals_hip_debug_clock(self.h, int(n_workgroups), C.byref(cyc), C.byref(ghz)))
+        return cyc.value, ghz.value
 
     @property
     def stream(self):

@@ -5,9 +5,9 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcals_hip.so")
-SOURCES = ["mttkrp_kernel.hip", "model_kernels.hip", "cals_hip_engine.cpp"]
+SOURCES = ["mttkrp_kernel.hip", "mttkrp_kernel_v2.hip", "mttkrp_kernel_v3.hip", "model_kernels.hip", "cals_hip_engine.cpp"]
 HEADERS = ["cals_hip_internal.h", os.path.join("..", "..", "include", "cals_hip.h")]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-Wall", "-Wno-unused-result"]
 
 
 def _newer(target, deps):
@@ -26,7 +26,10 @@ def build(force=False, verbose=False):
         src = os.path.join(CSRC, s)
         obj = os.path.join(HERE, "build", os.path.splitext(s)[0] + ".o")
         if force or _newer(obj, [src] + hdrs):
-            cmd = [hipcc] + FLAGS + ["-x", "hip", "-c", src, "-o", obj]
+            extra = ["-DCALS_V3_RING=%s" % os.environ["CALS_V3_RING"]] if os.environ.get("CALS_V3_RING") else []
+            if os.environ.get("CALS_DIAG"):
+                extra.append("-DCALS_DIAG=1")
+            cmd = [hipcc] + FLAGS + extra + ["-x", "hip", "-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd))
             subprocess.check_call(cmd)

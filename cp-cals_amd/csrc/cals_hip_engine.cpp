@@ -13,6 +13,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <string>
@@ -41,7 +42,8 @@ struct ModeLayout {
   int A = 0, Ap = 0, Mp = 0;
   long long S = 1;
   double *Xp = nullptr;
-  int MT = 0, m_blocks = 1, ldPart = 0;
+  int MT = 0, m_blocks = 1, ldPart = 0;        // v1 tiling (8 waves, one workgroup per CU)
+  int MT2 = 0, m_blocks2 = 1, k_big2 = 0;      // v2 tiling (two 4-wave workgroups per CU)
 };
 
 struct EventPair {
@@ -62,6 +64,7 @@ struct cals_hip_engine {
   int64_t buffer = 0;
   int device = 0;
   int n_cu = 256;
+  int mttkrp_kernel = 4;  // CALS_MTTKRP_KERNEL: 4 = v3 schedule (default), 1 = v1, 2/3 = v2 tilings
   hipStream_t stream = nullptr;
   std::string err;
   cals_hip_params prm{};
@@ -82,6 +85,7 @@ struct cals_hip_engine {
   size_t partial_elems = 0;
   double *krp_ws = nullptr;
   size_t krp_elems = 0;
+  unsigned long long *dbg_clock = nullptr;  // CALS_MTTKRP_CLOCK=1: in-kernel clock stamps
 
   ModelTable mt{};
   int max_slots = 0;
@@ -269,7 +273,9 @@ Geo geometry(const cals_hip_engine *e, int mode, int64_t R) {
   Geo g;
   g.NB = (int)((R + CALS_BN - 1) / CALS_BN);
   const long long U = (long long)(L.Ap / 16) * L.S;
-  long long T = e->n_cu / std::max(1, g.NB * L.m_blocks);
+  long long T = (e->mttkrp_kernel == 3)   ? (2 * e->n_cu) / std::max(1, g.NB)
+                : (e->mttkrp_kernel == 2) ? (2 * e->n_cu) / std::max(1, g.NB * L.m_blocks2)
+                                          : e->n_cu / std::max(1, g.NB * L.m_blocks);
   if (T < 1) T = 1;
   if (T > U) T = U;
   g.T = (int)T;
@@ -317,12 +323,28 @@ int launch_mttkrp(cals_hip_engine *e, int mode, int64_t R, Geo *geo_out) {
   a.T = g.T;
   a.ldPart = L.ldPart;
   a.grid = g.NB * g.T;
-  if ((size_t)a.grid * (size_t)L.ldPart * CALS_BN > e->partial_elems)
+  a.dbg_no_units = getenv("CALS_MTTKRP_NO_UNITS") ? 1 : 0;
+  a.dbg_clock = e->dbg_clock;
+  a.dbg_no_dma = getenv("CALS_MTTKRP_NO_DMA") ? 1 : 0;
+  a.dbg_no_stagger = getenv("CALS_MTTKRP_NO_STAGGER") ? 1 : 0;
+  a.dbg_no_barrier = getenv("CALS_MTTKRP_NO_BARRIER") ? 1 : 0;
+  if (e->mttkrp_kernel == 2 || e->mttkrp_kernel == 3) {
+    a.m_blocks = L.m_blocks2;
+    a.k_big = L.k_big2;
+    a.loop_mblocks = (e->mttkrp_kernel == 3) ? 1 : 0;
+    a.grid = a.loop_mblocks ? g.NB * g.T : g.NB * g.T * L.m_blocks2;
+  }
+  if ((size_t)g.NB * g.T * (size_t)L.ldPart * CALS_BN > e->partial_elems)
     return fail(e, CALS_HIP_ERR_STATE, "internal: partial buffer too small");
   double total = 1.0;
   for (int n = 0; n < e->n_modes; n++) total *= (double)e->modes[n];
   const int pk = prof_begin(e, 0, 2.0 * total * (double)R);
-  HIPCHK(mttkrp_launch(L.MT, L.m_blocks, a, e->stream));
+  if (e->mttkrp_kernel == 4)
+    HIPCHK(mttkrp3_launch(L.MT, L.m_blocks, a, e->stream));
+  else if (e->mttkrp_kernel >= 2)
+    HIPCHK(mttkrp2_launch(L.MT2, a, e->stream));
+  else
+    HIPCHK(mttkrp_launch(L.MT, L.m_blocks, a, e->stream));
   prof_end(e, pk);
   if (geo_out) *geo_out = g;
   return CALS_HIP_OK;
@@ -683,6 +705,9 @@ int cals_hip_create(cals_hip_engine **out, int n_modes, const int64_t *modes, in
     L.MT = mttkrp_pick_mt((m_tiles + L.m_blocks - 1) / L.m_blocks);
     if (L.MT == 0) return fail(e, CALS_HIP_ERR_ARG, "internal: no MTTKRP tile for this mode size");
     L.ldPart = L.m_blocks * 16 * L.MT;
+    L.m_blocks2 = (m_tiles + 9) / 10;
+    L.MT2 = (m_tiles + L.m_blocks2 - 1) / L.m_blocks2;
+    L.k_big2 = m_tiles - L.m_blocks2 * (L.MT2 - 1);
     part_rows_max = std::max<size_t>(part_rows_max, (size_t)L.ldPart * (size_t)L.m_blocks);
     if (L.s_modes.size() > 1) krp_max = std::max<size_t>(krp_max, (size_t)L.S * (size_t)buffer_size);
   }
@@ -695,7 +720,14 @@ int cals_hip_create(cals_hip_engine **out, int n_modes, const int64_t *modes, in
   const size_t nb_max = (size_t)((buffer_size + CALS_BN - 1) / CALS_BN);
   size_t ld_max = 0;
   for (int n = 0; n < n_modes; n++) ld_max = std::max<size_t>(ld_max, (size_t)e->lay[n].ldPart);
-  e->partial_elems = std::max<size_t>((size_t)e->n_cu, nb_max) * ld_max * CALS_BN;
+  e->partial_elems = std::max<size_t>((size_t)2 * e->n_cu, nb_max) * ld_max * CALS_BN;
+  if (getenv("CALS_MTTKRP_CLOCK")) {
+    if ((rc = dev_alloc(e, &e->dbg_clock, (size_t)16384))) return rc;
+  }
+  if (const char *k = getenv("CALS_MTTKRP_KERNEL")) {
+    const int v = atoi(k);
+    e->mttkrp_kernel = (v >= 2 && v <= 4) ? v : 1;
+  }
   (void)part_rows_max;
   if ((rc = dev_alloc(e, &e->partial, e->partial_elems))) return rc;
   if (krp_max) {
@@ -1044,6 +1076,50 @@ int cals_hip_reset_kernel_stats(cals_hip_engine *e) {
 }
 
 void *cals_hip_stream(cals_hip_engine *e) { return e ? (void *)e->stream : nullptr; }
+
+int cals_hip_debug_clock(cals_hip_engine *e, int n_workgroups, double *cycles_median, double *ghz_median) {
+  if (!e || !e->dbg_clock || n_workgroups < 1 || n_workgroups > 4096) return CALS_HIP_ERR_ARG;
+  std::vector<unsigned long long> h((size_t)2 * n_workgroups);
+  HIPCHK(hipMemcpy(h.data(), e->dbg_clock, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  std::vector<double> cyc, ghz;
+  for (int i = 0; i < n_workgroups; i++) {
+    if (h[2 * i + 1] == 0) continue;
+    cyc.push_back((double)h[2 * i]);
+    ghz.push_back((double)h[2 * i] / (double)h[2 * i + 1] * 0.1);
+  }
+  if (cyc.empty()) return CALS_HIP_ERR_STATE;
+  std::sort(cyc.begin(), cyc.end());
+  std::sort(ghz.begin(), ghz.end());
+  *cycles_median = cyc[cyc.size() / 2];
+  *ghz_median = ghz[ghz.size() / 2];
+  if (getenv("CALS_MTTKRP_STAGE_DUMP")) {
+    std::vector<unsigned long long> h3(32 * 8 * 3);
+    (void)hipMemcpy(h3.data(), e->dbg_clock + 4096, h3.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    for (int w = 0; w < 32 * 8; w += 13)
+      printf("wg %d wave %d: stages %llu, vmcnt-wait cycles/stage %.0f, barrier cycles/stage %.0f\n", w / 8, w % 8,
+             h3[3 * w + 2], (double)h3[3 * w] / (double)std::max(1ull, h3[3 * w + 2]),
+             (double)h3[3 * w + 1] / (double)std::max(1ull, h3[3 * w + 2]));
+  }
+  if (getenv("CALS_MTTKRP_V3_DUMP")) {
+    std::vector<unsigned long long> h4(32 * 8 * 5);
+    (void)hipMemcpy(h4.data(), e->dbg_clock + 8192, h4.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    for (int w = 0; w < 32 * 8; w += 11) {
+      const double n = (double)std::max(1ull, h4[5 * w + 4]);
+      printf("wg %d wave %d: units %.0f | per unit: barrier %.0f, top %.0f, half1 %.0f, half2 %.0f cycles\n", w / 8, w % 8, n,
+             h4[5 * w] / n, h4[5 * w + 1] / n, h4[5 * w + 2] / n, h4[5 * w + 3] / n);
+    }
+  }
+  if (getenv("CALS_MTTKRP_CLOCK_DUMP")) {
+    std::vector<unsigned long long> h2((size_t)2 * n_workgroups);
+    (void)hipMemcpy(h2.data(), e->dbg_clock + 4096, h2.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    unsigned long long r_min = ~0ull;
+    for (int i = 0; i < n_workgroups; i++) if (h2[2 * i] && h2[2 * i] < r_min) r_min = h2[2 * i];
+    for (int i = 0; i < n_workgroups; i++)
+      printf("wg %d start_us %.2f dur_us %.2f hwid 0x%llx\n", i, (double)(h2[2 * i] - r_min) * 0.01,
+             (double)h[2 * i + 1] * 0.01, h2[2 * i + 1]);
+  }
+  return CALS_HIP_OK;
+}
 
 int64_t cals_hip_host_first_fit(const int64_t *occupancy, int64_t n_cols, int64_t rank) {
   if (!occupancy || n_cols < 1 || rank < 1) return -1;

@@ -7,7 +7,7 @@
 
 #define CALS_MAX_MODES 8
 #define CALS_RMAX 32          // rank limit of the batched per-model kernels; Gramian store ld
-#define CALS_BN 128           // columns of the multi-factor per MTTKRP workgroup (4 waves x 32)
+#define CALS_BN 128           // columns of the multi-factor per MTTKRP workgroup
 
 namespace calship {
 
@@ -24,13 +24,25 @@ struct MttkrpArgs {
   int R;             // active columns
   int NB, T;         // column blocks, team size (workgroups per column block)
   int ldPart;        // rows of one partial tile (= m_blocks * 16 * MT)
-  int grid;          // NB * T
+  int grid;          // NB * T (v1) / NB * m_blocks * T (v2)
+  int m_blocks;      // v2 only: workgroup rows over M ...
+  int k_big;         // ... the first k_big of them have MT tiles, the rest MT - 1
+  int loop_mblocks;  // v2: 1 = each workgroup walks all M blocks (grid = NB * T)
+  int dbg_no_units;  // timing diagnostics only: skip the unit loop (prologue + epilogue cost)
+  int dbg_no_stagger;  // v3: 1 = all waves take the barrier mid-slab (A/B test of the stagger)
+  int dbg_no_barrier;  // timing diagnostics only (v3): drop the per-stage barrier (results garbage)
+  int dbg_no_dma;    // timing diagnostics only (v3): skip the steady-state LDS-DMA (results garbage)
+  unsigned long long *dbg_clock;  // diagnostics: per workgroup {s_memtime, s_memrealtime} deltas
 };
 
 // smallest supported tile count >= mt (0 if mt > max): instantiated MT values
 int mttkrp_pick_mt(int m_tiles);
 size_t mttkrp_lds_bytes(int MT);
 hipError_t mttkrp_launch(int MT, int m_blocks, const MttkrpArgs &a, hipStream_t st);
+// v2 tiling (mttkrp_kernel_v2.hip): two 4-wave workgroups per CU, MT <= 10
+hipError_t mttkrp2_launch(int MT, const MttkrpArgs &a, hipStream_t st);
+// v3 schedule (mttkrp_kernel_v3.hip): v1's tiling, 3-buffer ring, mid-stage barrier
+hipError_t mttkrp3_launch(int MT, int m_blocks, const MttkrpArgs &a, hipStream_t st);
 
 // Q[s,c] for N > 3: Khatri-Rao of the streamed modes' factors (first streamed mode fastest)
 struct KrpArgs {

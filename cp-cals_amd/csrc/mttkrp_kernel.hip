@@ -45,10 +45,48 @@ struct MtCfg {
 #define GLOBAL_AS __attribute__((address_space(1)))
 #define LDS_AS __attribute__((address_space(3)))
 
+// Hand-pipelined A-operand stream for one slab (VAR 4): ds_read_b64 into a ring of D registers,
+// each MFMA preceded by a COUNTED s_waitcnt lgkmcnt(n) (LDS returns in order, so "all but the n
+// youngest reads" is exactly "operand I has landed").  hipcc's own waits for this pattern are
+// lgkmcnt(0), which also waits for the read issued a few cycles earlier and stalls the wave for a
+// full LDS latency every few MFMAs.  The reads are inline asm (invisible to hipcc's counters), so
+// every wait is placed here; sched_barrier(0) keeps the MFMA below its wait (guide rule 18).
+template <int MT, int LDL, int D, int I0, int I1>
+struct SlabPipe {
+  static __device__ __forceinline__ void run(v4d (&acc)[MT], double (&ring)[D], const double (&bq)[4],
+                                             unsigned base) {
+    if constexpr (I0 < I1) {
+      constexpr int N = 4 * MT;
+      constexpr int outstanding = (D - 1 < N - 1 - I0) ? D - 1 : N - 1 - I0;
+      asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(outstanding));
+      __builtin_amdgcn_sched_barrier(0);
+      constexpr int q = I0 / MT, t = I0 % MT;
+      acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ring[I0 % D], bq[q], acc[t], 0, 0, 0);
+      if constexpr (I0 + D < N) {
+        constexpr int qn = (I0 + D) / MT, tn = (I0 + D) % MT;
+        asm volatile("ds_read_b64 %0, %1 offset:%2"
+                     : "=v"(ring[I0 % D])
+                     : "v"(base), "i"(((4 * qn) * LDL + 16 * tn) * 8));
+      }
+      SlabPipe<MT, LDL, D, I0 + 1, I1>::run(acc, ring, bq, base);
+    }
+  }
+  static __device__ __forceinline__ void preload(double (&ring)[D], unsigned base) {
+    if constexpr (I0 < I1) {
+      constexpr int q = I0 / MT, t = I0 % MT;
+      asm volatile("ds_read_b64 %0, %1 offset:%2"
+                   : "=v"(ring[I0 % D])
+                   : "v"(base), "i"(((4 * q) * LDL + 16 * t) * 8));
+      SlabPipe<MT, LDL, D, I0 + 1, I1>::preload(ring, base);
+    }
+  }
+};
+
 // VAR (tuning variants, selected with CALS_MTTKRP_VARIANT):
 //   bit 0: A-operand reads are unmerged ds_read_b64 software-pipelined PF MFMAs ahead
 //   bit 1: the next stage's LDS-DMA is issued after the first MFMA block of the current stage
 //          instead of before it
+//   4    : as 3, with the hand-pipelined inline-asm operand stream (SlabPipe) and counted waits
 template <int MT, int VAR>
 __global__ void __launch_bounds__(512, 2) mttkrp_kernel(const MttkrpArgs a) {
   typedef MtCfg<MT> C;
@@ -57,6 +95,8 @@ __global__ void __launch_bounds__(512, 2) mttkrp_kernel(const MttkrpArgs a) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const unsigned long long dbg_t0 = a.dbg_clock ? __builtin_amdgcn_s_memtime() : 0ull;
+  const unsigned long long dbg_r0 = a.dbg_clock ? __builtin_amdgcn_s_memrealtime() : 0ull;
   const int krow = lane >> 4;   // MFMA k index of this lane (0..3)
   const int lcol = lane & 15;   // MFMA m (A operand) / n (B operand, C/D) index
 
@@ -74,7 +114,7 @@ __global__ void __launch_bounds__(512, 2) mttkrp_kernel(const MttkrpArgs a) {
   const long long S = a.S;
   const long long U = (long long)(a.Ap >> 4) * S;
   const long long u_begin = U * tm / a.T;
-  const long long u_end = U * (tm + 1) / a.T;
+  const long long u_end = a.dbg_no_units ? u_begin : U * (tm + 1) / a.T;
 
   // this lane's column
   const int col = nb * CALS_BN + wave * 16 + lcol;
@@ -153,6 +193,7 @@ __global__ void __launch_bounds__(512, 2) mttkrp_kernel(const MttkrpArgs a) {
 
   double preg[4];
   long long ab_loaded = -1;
+  unsigned long long dbg_wait = 0, dbg_bar = 0, dbg_stages = 0;
   const double *abase = lds + krow * C::LDL + lcol;
 
   while (u < u_end) {
@@ -179,7 +220,7 @@ __global__ void __launch_bounds__(512, 2) mttkrp_kernel(const MttkrpArgs a) {
     }
     const bool have_next = un < u_end;
     if (have_next) stage_of(un, ab_n, s_n, n_n);
-    if (!(VAR & 2) && have_next) {
+    if (VAR != 4 && !(VAR & 2) && have_next) {
       issue_stage(buf ^ 1, ab_n, s_n, n_n);
       issue_q(buf ^ 1, s_n, n_n);
     }
@@ -190,7 +231,23 @@ __global__ void __launch_bounds__(512, 2) mttkrp_kernel(const MttkrpArgs a) {
     for (int j = 0; j < n_c; ++j) {
       const double q0 = qlds[buf * C::QSTAGE + j * CALS_BN + wave * 16 + lcol];
       const double *sl = abase + buf * C::STAGE + j * C::SLAB;
-      if (VAR & 1) {
+      if (VAR == 4) {
+        double bq[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bq[q] = preg[q] * q0;
+        constexpr int D = (4 * MT) < 6 ? (4 * MT) : 6;
+        constexpr int SPLIT = (MT < 4 * MT) ? MT : 4 * MT;
+        double ring[D];
+        const unsigned base = (unsigned)(size_t)((LDS_AS const char *)sl);
+        asm volatile("" ::: "memory");  // q0 (and its compiler-inserted wait) stay above the asm reads
+        SlabPipe<MT, C::LDL, D, 0, D>::preload(ring, base);
+        SlabPipe<MT, C::LDL, D, 0, SPLIT>::run(acc, ring, bq, base);
+        if (j == 0 && have_next) {
+          issue_stage(buf ^ 1, ab_n, s_n, n_n);
+          issue_q(buf ^ 1, s_n, n_n);
+        }
+        SlabPipe<MT, C::LDL, D, SPLIT, 4 * MT>::run(acc, ring, bq, base);
+      } else if (VAR & 1) {
         double bq[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) bq[q] = preg[q] * q0;
@@ -233,8 +290,19 @@ __global__ void __launch_bounds__(512, 2) mttkrp_kernel(const MttkrpArgs a) {
       }
     }
 
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    if (a.dbg_clock) {  // diagnostics build path: where does the end of a stage go?
+      const unsigned long long s0 = __builtin_amdgcn_s_memtime();
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const unsigned long long s1 = __builtin_amdgcn_s_memtime();
+      __syncthreads();
+      const unsigned long long s2 = __builtin_amdgcn_s_memtime();
+      dbg_wait += s1 - s0;
+      dbg_bar += s2 - s1;
+      dbg_stages++;
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
     u = un;
     ab_c = ab_n;
     s_c = s_n;
@@ -242,6 +310,18 @@ __global__ void __launch_bounds__(512, 2) mttkrp_kernel(const MttkrpArgs a) {
     buf ^= 1;
   }
 
+  if (a.dbg_clock && lane == 0) {  // diagnostics only: shader clock held during the unit loop
+    const int wg = blockIdx.x + gridDim.x * blockIdx.y;
+    if (wave == 0) {
+      a.dbg_clock[2 * wg] = __builtin_amdgcn_s_memtime() - dbg_t0;
+      a.dbg_clock[2 * wg + 1] = __builtin_amdgcn_s_memrealtime() - dbg_r0;
+    }
+    if (wg < 32) {  // per-wave stage-end breakdown of the first 32 workgroups
+      a.dbg_clock[4096 + (wg * 8 + wave) * 3 + 0] = dbg_wait;
+      a.dbg_clock[4096 + (wg * 8 + wave) * 3 + 1] = dbg_bar;
+      a.dbg_clock[4096 + (wg * 8 + wave) * 3 + 2] = dbg_stages;
+    }
+  }
   // ---- epilogue: partial tile [ldPart x 128] of (nb, tm); f64 MFMA C/D layout:
   // lane holds D[row = (lane>>4) + 4*reg][col = lane&15]
   double *pt = a.partial + ((long long)(nb * a.T + tm)) * ((long long)a.ldPart * CALS_BN);
@@ -284,7 +364,7 @@ static int mttkrp_variant() {
   static int v = -1;
   if (v < 0) {
     const char *s = getenv("CALS_MTTKRP_VARIANT");
-    v = s ? atoi(s) & 3 : 3;
+    v = s ? atoi(s) & 7 : 3;
   }
   return v;
 }
@@ -292,10 +372,9 @@ static int mttkrp_variant() {
 template <int MT>
 static hipError_t launch_mt(int m_blocks, const MttkrpArgs &a, hipStream_t st) {
   switch (mttkrp_variant()) {
-    case 1: return launch_mt_var<MT, 1>(m_blocks, a, st);
-    case 2: return launch_mt_var<MT, 2>(m_blocks, a, st);
-    case 3: return launch_mt_var<MT, 3>(m_blocks, a, st);
-    default: return launch_mt_var<MT, 0>(m_blocks, a, st);
+    case 0: return launch_mt_var<MT, 0>(m_blocks, a, st);
+    case 4: return launch_mt_var<MT, 4>(m_blocks, a, st);
+    default: return launch_mt_var<MT, 3>(m_blocks, a, st);
   }
 }
 

@@ -162,6 +162,9 @@ int cals_hip_get_kernel_stats(cals_hip_engine *e, cals_hip_kernel_stats *out);
 int cals_hip_reset_kernel_stats(cals_hip_engine *e);
 /* hipStream_t the engine launches on (as void*), so callers can bracket it with their own events */
 void *cals_hip_stream(cals_hip_engine *e);
+/* diagnostics (CALS_MTTKRP_CLOCK=1 in the environment at create): median over workgroups of the
+ * shader cycles a MTTKRP workgroup ran and of the clock (GHz) it saw (s_memtime / s_memrealtime) */
+int cals_hip_debug_clock(cals_hip_engine *e, int n_workgroups, double *cycles_median, double *ghz_median);
 /* number of HIP devices visible (0 when none); never initialises a context on failure */
 int cals_hip_device_count(void);
 
