@@ -72,6 +72,10 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--cpu-sweeps", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl (= RCCL) for real multi-GPU runs; gloo only to rehearse the N>1 path")
+    ap.add_argument("--force-device0", action="store_true",
+                    help="rehearsal on a 1-GPU box: every rank uses cuda:0 (use with --dist-backend gloo)")
     args = ap.parse_args()
 
     import numpy as np
@@ -90,11 +94,19 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the CALS engine has no CPU fallback")
+    if args.force_device0:
+        local_rank = 0
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit("rank %d: LOCAL_RANK %d but only %d GPU(s) visible" % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+    red_dev = dev if (world == 1 or args.dist_backend == "nccl") else torch.device("cpu")
 
     modes, k_models, ls = WORKLOADS[args.workload]
     ranks = local_ranks(k_models)           # this rank's shard: models m = rank + world*k
@@ -124,7 +136,7 @@ def main():
     sharding.barrier()
     elapsed = time.perf_counter() - t0
 
-    value, t_max = sharding.aggregate_rate(args.steps, elapsed, device=dev)
+    value, t_max = sharding.aggregate_rate(args.steps, elapsed, device=red_dev)
     ks = eng.kernel_stats()
     eng.set_profiling(False)
 

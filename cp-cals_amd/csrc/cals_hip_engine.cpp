@@ -328,6 +328,7 @@ int launch_mttkrp(cals_hip_engine *e, int mode, int64_t R, Geo *geo_out) {
   a.dbg_no_dma = getenv("CALS_MTTKRP_NO_DMA") ? 1 : 0;
   a.dbg_no_stagger = getenv("CALS_MTTKRP_NO_STAGGER") ? 1 : 0;
   a.dbg_no_barrier = getenv("CALS_MTTKRP_NO_BARRIER") ? 1 : 0;
+  a.dbg_prio = getenv("CALS_MTTKRP_PRIO") ? atoi(getenv("CALS_MTTKRP_PRIO")) : 0;
   if (e->mttkrp_kernel == 2 || e->mttkrp_kernel == 3) {
     a.m_blocks = L.m_blocks2;
     a.k_big = L.k_big2;

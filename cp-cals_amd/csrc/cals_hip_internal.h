@@ -31,6 +31,7 @@ struct MttkrpArgs {
   int dbg_no_units;  // timing diagnostics only: skip the unit loop (prologue + epilogue cost)
   int dbg_no_stagger;  // v3: 1 = all waves take the barrier mid-slab (A/B test of the stagger)
   int dbg_no_barrier;  // timing diagnostics only (v3): drop the per-stage barrier (results garbage)
+  int dbg_prio;        // diagnostics (v3): 1 = s_setprio 1 for waves 4-7, 2 = for waves 0-3
   int dbg_no_dma;    // timing diagnostics only (v3): skip the steady-state LDS-DMA (results garbage)
   unsigned long long *dbg_clock;  // diagnostics: per workgroup {s_memtime, s_memrealtime} deltas
 };

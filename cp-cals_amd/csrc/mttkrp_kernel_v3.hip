@@ -302,6 +302,8 @@ __global__ void __launch_bounds__(512, 2) mttkrp3_kernel(const MttkrpArgs a) {
       if (s_2 >= S) { s_2 = 0; ab_2++; }
     }
   };
+  if (DIAG(a.dbg_prio == 1) && wave >= 4) __builtin_amdgcn_s_setprio(1);
+  if (DIAG(a.dbg_prio == 2) && wave < 4) __builtin_amdgcn_s_setprio(1);
   if (wave < 4 || DIAG(a.dbg_no_stagger))
     unit_loop.template operator()<false>();
   else
