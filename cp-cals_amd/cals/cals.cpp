@@ -3,6 +3,7 @@
 #include "cals.h"
 
 #include <chrono>
+#include <limits>
 
 #include "../../include/cals_hip.h"
 
@@ -20,6 +21,41 @@ void CalsParams::print() const {
   cout << "Line Search:     " << (line_search ? "true" : "false") << endl;
   if (line_search) cout << "-Line Search Interval: " << line_search_interval << " iterations" << endl;
   cout << "Device path:     MI355X HIP engine (device " << device << ")" << endl;
+  cout << "---------------------------------------" << endl;
+}
+
+double Timer::now() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+Tensor::Tensor(const std::string &file_name) {
+  std::ifstream file(file_name);
+  if (!file.is_open()) throw std::runtime_error("Tensor: cannot open " + file_name);
+  std::string line;
+  std::getline(file, line);
+  std::stringstream ss(line);
+  dim_t m;
+  while (ss >> m) modes.push_back(m);
+  n_elements = 1;
+  for (auto v : modes) n_elements *= v;
+  owned.reset(new double[n_elements]);
+  data = owned.get();
+  dim_t index = 0;
+  double val;
+  while (index < n_elements && file >> val) data[index++] = val;
+  if (index != n_elements) throw std::runtime_error("Tensor: " + file_name + " holds too few values");
+}
+
+void AlsParams::print() const {
+  using std::cout;
+  using std::endl;
+  cout << "---------------------------------------" << endl;
+  cout << "ALS parameters" << endl;
+  cout << "---------------------------------------" << endl;
+  cout << "Tolerance:        " << tol << endl;
+  cout << "Max Iterations:   " << max_iterations << endl;
+  cout << "Line Search:      " << (line_search ? "true" : "false") << endl;
+  cout << "Device path:      MI355X HIP engine (device " << device << ")" << endl;
   cout << "---------------------------------------" << endl;
 }
 
@@ -109,4 +145,193 @@ CalsReport cp_cals(const Tensor &X, KtensorQueue &kt_queue, CalsParams &p) {
   return rep;
 }
 
+
+// cp_als (include/als.h:190, src/als.cpp:19-289) on the device engine: one model in flight.
+AlsReport cp_als(const Tensor &X, Ktensor &ktensor, AlsParams &ap) {
+  CalsParams p;
+  p.update_method = ap.update_method;
+  p.max_iterations = ap.max_iterations;
+  p.tol = ap.tol;
+  p.cuda = ap.cuda;
+  p.buffer_size = ktensor.get_components();
+  p.line_search = ap.line_search;
+  p.line_search_interval = ap.line_search_interval;
+  p.line_search_step = ap.line_search_step;
+  p.line_search_method = ap.line_search_method;
+  p.force_max_iter = ap.force_max_iter;
+  p.device = ap.device;
+  KtensorQueue q;
+  q.emplace(ktensor);
+  CalsReport r = cp_cals(X, q, p);
+  AlsReport out;
+  out.iter = r.iter;
+  out.ls_performed = r.ls_performed;
+  out.ls_failed = r.ls_failed;
+  out.X_norm = r.X_norm;
+  out.total_time = r.total_time;
+  return out;
+}
+
+// ---------------------------------------------------------------------------------------------
+// linear sum assignment: Hungarian algorithm with row/column potentials, O(n^3)
+// ---------------------------------------------------------------------------------------------
+int solve_linear_sum_assignment(int n, const double *cost, bool maximize, int64_t *col_of_row) {
+  if (n < 1 || !cost || !col_of_row) return -2;
+  const double INF = std::numeric_limits<double>::infinity();
+  auto c = [&](int i, int j) {  // 1-based row i, column j; minimisation form
+    const double v = cost[(i - 1) + (size_t)n * (j - 1)];
+    return maximize ? -v : v;
+  };
+  for (int k = 0; k < n * n; k++)
+    if (!(cost[k] == cost[k]) || cost[k] == INF || cost[k] == -INF) return -2;
+  std::vector<double> u(n + 1, 0.0), v(n + 1, 0.0), minv(n + 1);
+  std::vector<int> p(n + 1, 0), way(n + 1, 0);
+  std::vector<char> used(n + 1);
+  for (int i = 1; i <= n; i++) {
+    p[0] = i;
+    int j0 = 0;
+    std::fill(minv.begin(), minv.end(), INF);
+    std::fill(used.begin(), used.end(), 0);
+    do {
+      used[j0] = 1;
+      const int i0 = p[j0];
+      double delta = INF;
+      int j1 = 0;
+      for (int j = 1; j <= n; j++) {
+        if (used[j]) continue;
+        const double cur = c(i0, j) - u[i0] - v[j];
+        if (cur < minv[j]) {
+          minv[j] = cur;
+          way[j] = j0;
+        }
+        if (minv[j] < delta) {
+          delta = minv[j];
+          j1 = j;
+        }
+      }
+      for (int j = 0; j <= n; j++) {
+        if (used[j]) {
+          u[p[j]] += delta;
+          v[j] -= delta;
+        } else
+          minv[j] -= delta;
+      }
+      j0 = j1;
+    } while (p[j0] != 0);
+    do {
+      const int j1 = way[j0];
+      p[j0] = p[j1];
+      j0 = j1;
+    } while (j0);
+  }
+  for (int j = 1; j <= n; j++) col_of_row[p[j] - 1] = j - 1;
+  return 0;
+}
+
+namespace utils {
+
+std::string mode_string(vector<dim_t> const &modes) {  // src/utils/utils.cpp:9-16
+  std::string m;
+  for (auto const &v : modes) m += std::to_string(v) + '-';
+  if (!m.empty()) m.pop_back();
+  return m;
+}
+
+Ktensor concatenate_ktensors(vector<Ktensor> const &ktensors) {  // src/utils/utils.cpp:18-38
+  const dim_t comp = ktensors[0].get_components();
+  Ktensor out(ktensors.size() * comp, ktensors[0].get_modes());
+  dim_t index = 0;
+  for (auto const &kt : ktensors) {
+    for (dim_t i = 0; i < comp; i++) out.get_lambda()[index * comp + i] = kt.get_lambda()[i];
+    for (dim_t m = 0; m < kt.get_n_modes(); m++)
+      for (dim_t c = 0; c < comp; c++)
+        for (dim_t r = 0; r < kt.get_factor(m).get_rows(); r++)
+          out.get_factor(m)(r, index * comp + c) = kt.get_factor(m)(r, c);
+    index++;
+  }
+  return out;
+}
+
+void generate_jk_ktensors(Ktensor const &reference_ktensor, vector<Ktensor> &jk_ktensor_v) {
+  // src/utils/utils.cpp:40-52: one copy per mode-0 slice, flagged jk(mode 0, fiber i)
+  const dim_t I0 = reference_ktensor.get_modes()[0];
+  if (I0 <= 1) throw std::string("Can't do Jack-knife with just one sample.");
+  for (dim_t i = 0; i < I0; i++) {
+    Ktensor copy(reference_ktensor);
+    copy.to_jk(0, i);
+    jk_ktensor_v.push_back(std::move(copy));
+  }
+}
+
+void jk_permutation_adjustment(Ktensor &ktensor, vector<Ktensor> &jk_ktensor_v) {
+  // src/utils/utils.cpp:54-101: match the columns of every replica to the overall model by
+  // maximising trace(P^T (Bov^T Bm + Cov^T Cm)), then reorder the replica's columns
+  const auto &modes = ktensor.get_modes();
+  const dim_t comp = ktensor.get_components();
+  const Matrix &Bov = ktensor.get_factor(1), &Cov = ktensor.get_factor(2);
+  for (dim_t m = 0; m < modes[0]; m++) {
+    Ktensor &kt = jk_ktensor_v[m];
+    const Matrix &Bm = kt.get_factor(1), &Cm = kt.get_factor(2);
+    std::vector<double> M(comp * comp, 0.0);
+    for (dim_t j = 0; j < comp; j++)
+      for (dim_t i = 0; i < comp; i++) {
+        double s = 0.0, t = 0.0;
+        for (dim_t r = 0; r < modes[1]; r++) s += Bov(r, i) * Bm(r, j);
+        for (dim_t r = 0; r < modes[2]; r++) t += Cov(r, i) * Cm(r, j);
+        M[i + comp * j] = s + t;
+      }
+    std::vector<int64_t> solved(comp);
+    solve_linear_sum_assignment((int)comp, M.data(), true, solved.data());
+    for (dim_t mode = 0; mode < ktensor.get_n_modes(); mode++) {
+      Matrix &f = kt.get_factor(mode);
+      Matrix copy(f.get_rows(), f.get_cols());
+      copy.copy(f);
+      for (dim_t cur = 0; cur < comp; cur++) {
+        const dim_t swap = (dim_t)solved[cur];
+        if (swap != cur)
+          for (dim_t r = 0; r < f.get_rows(); r++) f(r, cur) = copy(r, swap);
+      }
+    }
+  }
+}
+
+}  // namespace utils
+
+JKReport jk_cp_cals(const Tensor &X, vector<Ktensor> &kt_vector, CalsParams &cals_params) {
+  vector<Ktensor> ktensors(kt_vector);
+  for (auto &k : ktensors) {
+    k.denormalize();
+    k.normalize();
+  }
+  Timer pre, run;
+  pre.start();
+  vector<vector<Ktensor>> jk_input(ktensors.size());
+  for (size_t i = 0; i < ktensors.size(); i++) utils::generate_jk_ktensors(ktensors[i], jk_input[i]);
+  KtensorQueue queue;
+  for (auto &k : jk_input)
+    for (auto &m : k) queue.emplace(m);
+  pre.stop();
+  run.start();
+  cp_cals(X, queue, cals_params);
+  run.stop();
+  for (auto &k : jk_input)
+    for (auto &m : k) {
+      m.set_jk_fiber(0.0);
+      m.denormalize();
+      m.normalize();
+      m.set_jk_fiber(NAN);
+    }
+  for (size_t i = 0; i < ktensors.size(); i++) utils::jk_permutation_adjustment(ktensors[i], jk_input[i]);
+  JKReport rep;
+  rep.jk_time.pre_als_time = pre.get_time();
+  rep.jk_time.als_time = run.get_time();
+  rep.results = std::move(jk_input);
+  return rep;
+}
+
 }  // namespace cals
+
+// C entry point of the assignment solver (tests bind it with ctypes)
+extern "C" int cals_lsap_solve(int n, const double *cost_colmajor, int maximize, int64_t *col_of_row) {
+  return cals::solve_linear_sum_assignment(n, cost_colmajor, maximize != 0, col_of_row);
+}

@@ -18,6 +18,8 @@
 #include <random>
 #include <stdexcept>
 #include <string>
+#include <fstream>
+#include <sstream>
 #include <vector>
 
 typedef size_t dim_t;  // include/definitions.h:18
@@ -65,6 +67,9 @@ class Tensor {
       data = owned.get();
     }
   }
+  // text file: first line = mode sizes separated by blanks, then one value per line, mode 0
+  // fastest (src/tensor.cpp:35-65)
+  explicit Tensor(const std::string &file_name);
   Tensor(Tensor &&) = default;
   Tensor &operator=(Tensor &&) = default;
   Tensor(const Tensor &rhs) : n_elements(rhs.n_elements), modes(rhs.modes), rank(rhs.rank) {
@@ -244,6 +249,32 @@ class Ktensor {
     jk.fiber = fiber;
     return *this;
   }
+  // include/ktensor.h:270-303: the jk model without its fiber row (one row less in the jk mode)
+  Ktensor to_regular() const {
+    if (!jk.enabled) return *this;
+    vector<dim_t> reg_modes(modes);
+    reg_modes[jk.mode] -= 1;
+    Ktensor out(components, reg_modes);
+    for (dim_t f = 0; f < modes.size(); f++)
+      for (dim_t c = 0; c < components; c++)
+        for (dim_t i = 0, o = 0; i < modes[f]; i++) {
+          if (f == jk.mode && i == jk.fiber) continue;
+          out.factors[f](o++, c) = factors[f](i, c);
+        }
+    out.lambda = lambda;
+    return out;
+  }
+  // Ktensor::copy (src/ktensor.cpp:163-181): state, lambda and factors; not id, not jk
+  Ktensor &copy(const Ktensor &rhs) {
+    approx_error = rhs.approx_error;
+    fit = rhs.fit;
+    old_fit = rhs.old_fit;
+    iters = rhs.iters;
+    normalized = rhs.normalized;
+    lambda = rhs.lambda;
+    for (dim_t f = 0; f < factors.size(); f++) factors[f].copy(rhs.factors[f]);
+    return *this;
+  }
   Tensor to_tensor() const {  // ktensor.cpp:32-64
     Tensor X(modes);
     vector<dim_t> idx(modes.size(), 0);
@@ -310,6 +341,72 @@ struct CalsParams {
   int device{0};  // added: HIP device ordinal (default preserves single-GPU behaviour)
   void print() const;
 };
+
+// include/timer.h
+class Timer {
+  double t0{0.0}, elapsed{0.0};
+  static double now();
+
+ public:
+  void start() { t0 = now(); }
+  void stop() { elapsed = now() - t0; }
+  void reset() { elapsed = 0.0; }
+  double get_time() const { return elapsed; }
+};
+
+// include/als.h:142-166 / :27-63 (fields on the path).  cp_als here is the same device engine with
+// a single model in flight (the reference's tests demand CALS == ALS per model anyway).
+struct AlsParams {
+  update::UPDATE_METHOD update_method{update::UNCONSTRAINED};
+  mttkrp::MTTKRP_METHOD mttkrp_method{mttkrp::AUTO};
+  dim_t max_iterations{200};
+  double tol{1e-7};
+  bool cuda{true};
+  bool line_search{false};
+  int line_search_interval{5};
+  double line_search_step{0};
+  ls::LS_METHOD line_search_method{ls::NO_ERROR_CHECKING};
+  bool force_max_iter{false};
+  bool suppress_lut_warning{false};
+  int device{0};
+  void print() const;
+};
+struct AlsReport {
+  dim_t iter{0};
+  dim_t ls_performed{0}, ls_failed{0};
+  double X_norm{0.0};
+  double total_time{0.0};
+};
+AlsReport cp_als(const Tensor &X, Ktensor &ktensor, AlsParams &als_params);
+
+// include/als.h:22-25, 168-170
+struct JKTime {
+  double pre_als_time{0.0};
+  double als_time{0.0};
+};
+struct JKReport {
+  JKTime jk_time;
+  vector<vector<Ktensor>> results;
+};
+
+namespace utils {  // include/utils/utils.h:17-23
+std::string mode_string(vector<dim_t> const &modes);
+Ktensor concatenate_ktensors(vector<Ktensor> const &ktensors);
+void generate_jk_ktensors(Ktensor const &reference_ktensor, vector<Ktensor> &jk_ktensor_v);
+void jk_permutation_adjustment(Ktensor &ktensor, vector<Ktensor> &jk_ktensor_v);
+}  // namespace utils
+
+// Linear sum assignment on an n x n col-major cost matrix (what the reference gets from SciPy's
+// rectangular_lsap, extern/rectangular_lsap): col_of_row[i] = column assigned to row i.
+// Own implementation (Hungarian / Kuhn-Munkres with potentials), returns 0 on success.
+int solve_linear_sum_assignment(int n, const double *cost_colmajor, bool maximize, int64_t *col_of_row);
+
+inline void set_threads(int) {}   // include/cals_blas.h:184-186: host BLAS threads; no meaning here
+inline int get_threads() { return 1; }
+
+// Jackknife driver (src/cals.cpp:397-446): for every model of kt_vector, modes[0] jackknife
+// replicas fitted in ONE cp_cals call, then re-normalised and column-matched to the original.
+JKReport jk_cp_cals(const Tensor &X, vector<Ktensor> &kt_vector, CalsParams &cals_params);
 
 // Fits every Ktensor of the queue to X with concurrent ALS on the GPU and overwrites it with the
 // result (factors, lambda, error, fit, iters); the queue is empty on return (include/cals.h:183-196).

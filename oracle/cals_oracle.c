@@ -1079,6 +1079,102 @@ int or_cp_cals(const double *X, int n_modes, const int64_t *modes, or_model *mod
   return 0;
 }
 
+/* ------------------------------------------------------------------------------------------ */
+/* jackknife driver                                                                            */
+/* ------------------------------------------------------------------------------------------ */
+int or_lsap_bruteforce(int n, const double *cost, int maximize, int64_t *col_of_row) {
+  if (n < 1 || n > 9) return -1;
+  int perm[9], best[9];
+  for (int i = 0; i < n; i++) perm[i] = i;
+  double best_v = 0.0;
+  int have = 0;
+  for (;;) {
+    double v = 0.0;
+    for (int i = 0; i < n; i++) v += cost[i + n * perm[i]];
+    if (!have || (maximize ? v > best_v : v < best_v)) {
+      best_v = v;
+      have = 1;
+      memcpy(best, perm, sizeof(int) * (size_t)n);
+    }
+    /* next permutation (lexicographic) */
+    int k = n - 2;
+    while (k >= 0 && perm[k] > perm[k + 1]) k--;
+    if (k < 0) break;
+    int l = n - 1;
+    while (perm[l] < perm[k]) l--;
+    int t = perm[k]; perm[k] = perm[l]; perm[l] = t;
+    for (int a = k + 1, b = n - 1; a < b; a++, b--) { t = perm[a]; perm[a] = perm[b]; perm[b] = t; }
+  }
+  for (int i = 0; i < n; i++) col_of_row[i] = best[i];
+  return 0;
+}
+
+int or_jk_cp_cals(const double *X, int n_modes, const int64_t *modes, const or_model *kt_vector,
+                  int64_t n_models, const or_params *params, or_model *results, or_report *rep) {
+  const int64_t I0 = modes[0];
+  if (n_modes < 3 || I0 <= 1) return -1;
+  /* ktensors(kt_vector): denormalize(); normalize()  (cals.cpp:399-405) */
+  kt_t *over = (kt_t *)calloc((size_t)n_models, sizeof(kt_t));
+  for (int64_t k = 0; k < n_models; k++) {
+    kt_alloc(&over[k], kt_vector[k].rank, n_modes, modes);
+    for (int n = 0; n < n_modes; n++)
+      memcpy(over[k].fac[n], kt_vector[k].factors[n], sizeof(double) * (size_t)(modes[n] * kt_vector[k].rank));
+    memcpy(over[k].lambda, kt_vector[k].lambda, sizeof(double) * (size_t)kt_vector[k].rank);
+    or_denormalize(over[k].fac[0], modes[0], over[k].rank, over[k].lambda);
+    or_normalize_all(over[k].fac, n_modes, modes, over[k].rank, over[k].lambda);
+    /* generate_jk_ktensors (utils.cpp:40-52): plain copies flagged jk(0, i) */
+    for (int64_t i = 0; i < I0; i++) {
+      or_model *m = &results[k * I0 + i];
+      m->rank = over[k].rank;
+      for (int n = 0; n < n_modes; n++)
+        memcpy(m->factors[n], over[k].fac[n], sizeof(double) * (size_t)(modes[n] * m->rank));
+      memcpy(m->lambda, over[k].lambda, sizeof(double) * (size_t)m->rank);
+      m->jk_enabled = 1;
+      m->jk_mode = 0;
+      m->jk_fiber = i;
+    }
+  }
+  int rc = or_cp_cals(X, n_modes, modes, results, n_models * I0, params, rep);
+  if (rc) return rc;
+  for (int64_t k = 0; k < n_models; k++) {
+    const int64_t r = over[k].rank;
+    for (int64_t i = 0; i < I0; i++) { /* cals.cpp:431-437 */
+      or_model *m = &results[k * I0 + i];
+      for (int64_t c = 0; c < r; c++) m->factors[0][i + I0 * c] *= 0.0;
+      or_denormalize(m->factors[0], I0, r, m->lambda);
+      or_normalize_all(m->factors, n_modes, modes, r, m->lambda);
+      for (int64_t c = 0; c < r; c++) m->factors[0][i + I0 * c] = NAN;
+    }
+    /* jk_permutation_adjustment, utils.cpp:54-101 */
+    for (int64_t i = 0; i < I0; i++) {
+      or_model *m = &results[k * I0 + i];
+      double *M = (double *)xmalloc(sizeof(double) * (size_t)(r * r));
+      for (int64_t b = 0; b < r; b++)
+        for (int64_t a = 0; a < r; a++) {
+          double s = 0.0, t = 0.0;
+          for (int64_t q = 0; q < modes[1]; q++) s += over[k].fac[1][q + modes[1] * a] * m->factors[1][q + modes[1] * b];
+          for (int64_t q = 0; q < modes[2]; q++) t += over[k].fac[2][q + modes[2] * a] * m->factors[2][q + modes[2] * b];
+          M[a + r * b] = s + t;
+        }
+      int64_t solved[9];
+      if (or_lsap_bruteforce((int)r, M, 1, solved)) { free(M); return -3; }
+      free(M);
+      for (int n = 0; n < n_modes; n++) {
+        const size_t bytes = sizeof(double) * (size_t)(modes[n] * r);
+        double *copy = (double *)xmalloc(bytes);
+        memcpy(copy, m->factors[n], bytes);
+        for (int64_t cur = 0; cur < r; cur++)
+          if (solved[cur] != cur)
+            memcpy(m->factors[n] + modes[n] * cur, copy + modes[n] * solved[cur], sizeof(double) * (size_t)modes[n]);
+        free(copy);
+      }
+    }
+    kt_free(&over[k]);
+  }
+  free(over);
+  return 0;
+}
+
 void or_set_threads(int n) {
 #ifdef _OPENMP
   omp_set_num_threads(n > 0 ? n : 1);

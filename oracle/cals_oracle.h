@@ -119,6 +119,16 @@ int or_cp_als(const double *X, int n_modes, const int64_t *modes, or_model *mode
 int or_cp_cals(const double *X, int n_modes, const int64_t *modes, or_model *models,
                int64_t n_models, const or_params *params, or_report *rep);
 
+/* jk_cp_cals, src/cals.cpp:397-446: results must hold n_models * modes[0] models with
+ * caller-allocated factors (I_n x rank) and lambda; they receive the jackknife replicas (replica i of
+ * model k at results[k * modes[0] + i]) after re-normalisation and column matching
+ * (utils::jk_permutation_adjustment, src/utils/utils.cpp:54-101).  The assignment problem, which
+ * the reference hands to SciPy's rectangular_lsap (extern/), is solved here by exhaustive search
+ * (rank <= 9): an independent check of the product's Hungarian solver. */
+int or_lsap_bruteforce(int n, const double *cost_colmajor, int maximize, int64_t *col_of_row);
+int or_jk_cp_cals(const double *X, int n_modes, const int64_t *modes, const or_model *kt_vector,
+                  int64_t n_models, const or_params *params, or_model *results, or_report *rep);
+
 #ifdef __cplusplus
 }
 #endif

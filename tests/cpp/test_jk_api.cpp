@@ -1,0 +1,130 @@
+// cals::jk_cp_cals (C++ layer -> C ABI -> HIP engine) against the oracle's jk_cp_cals: the
+// reference's CalsJackknifingTests.FunctionCorrectness (tests/cals/test_cals.cpp:299-362) with the
+// oracle in place of jk_cp_als.  Test infrastructure: links oracle/liboracle.so.
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "../../cp-cals_amd/cals/cals.h"
+#include "../../oracle/cals_oracle.h"
+
+static uint64_t g_state = 12345;
+static double next_pm1() {
+  uint64_t z = (g_state += 0x9E3779B97F4A7C15ull);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  return 2.0 * ((double)(z >> 11) * (1.0 / 9007199254740992.0)) - 1.0;
+}
+
+int main() {
+  const dim_t n_ktensors = 3, components = 5;
+  std::vector<dim_t> modes = {10, 21, 20};
+  const int64_t omodes[3] = {10, 21, 20};
+  cals::Ktensor P(components, modes);
+  P.fill([]() { return next_pm1(); });
+  cals::Tensor T = P.to_tensor();
+
+  std::vector<cals::Ktensor> refs;
+  for (dim_t k = 0; k < n_ktensors; k++) {
+    refs.emplace_back(components, modes);
+    refs.back().fill([]() { return next_pm1(); });
+  }
+  cals::CalsParams prm;
+  prm.max_iterations = 40;
+  prm.tol = 1e-4;
+  prm.buffer_size = 18;
+  prm.force_max_iter = true;
+  // first fit the overall models (test_cals.cpp:339-340 does this with cp_als)
+  cals::AlsParams ap;
+  ap.max_iterations = 40;
+  ap.tol = 1e-4;
+  ap.force_max_iter = true;
+  try {
+    for (auto &k : refs) cals::cp_als(T, k, ap);
+  } catch (const std::exception &e) {
+    fprintf(stderr, "cp_als threw: %s\n", e.what());
+    return 2;
+  }
+
+  // oracle inputs = the fitted overall models
+  std::vector<std::vector<std::vector<double>>> of(n_ktensors);
+  std::vector<std::vector<double>> ol(n_ktensors);
+  std::vector<or_model> om(n_ktensors);
+  for (dim_t k = 0; k < n_ktensors; k++) {
+    memset(&om[k], 0, sizeof(or_model));
+    om[k].rank = components;
+    of[k].resize(3);
+    for (int n = 0; n < 3; n++) {
+      const auto &f = refs[k].get_factor(n);
+      of[k][n].assign(f.get_data(), f.get_data() + f.get_n_elements());
+      om[k].factors[n] = of[k][n].data();
+    }
+    ol[k] = refs[k].get_lambda();
+    om[k].lambda = ol[k].data();
+  }
+  const size_t n_res = n_ktensors * modes[0];
+  std::vector<or_model> res(n_res);
+  std::vector<std::vector<std::vector<double>>> rf(n_res);
+  std::vector<std::vector<double>> rl(n_res);
+  for (size_t i = 0; i < n_res; i++) {
+    memset(&res[i], 0, sizeof(or_model));
+    rf[i].resize(3);
+    for (int n = 0; n < 3; n++) {
+      rf[i][n].assign(modes[n] * components, 0.0);
+      res[i].factors[n] = rf[i][n].data();
+    }
+    rl[i].assign(components, 0.0);
+    res[i].lambda = rl[i].data();
+  }
+  or_params op;
+  or_default_params(&op);
+  op.max_iterations = 40;
+  op.tol = 1e-4;
+  op.buffer_size = 18;
+  op.force_max_iter = 1;
+  op.mttkrp_method = OR_MTTKRP;
+  or_set_threads(1);
+  or_report orep;
+  if (or_jk_cp_cals(T.get_data(), 3, omodes, om.data(), (int64_t)n_ktensors, &op, res.data(), &orep)) {
+    fprintf(stderr, "oracle jk failed\n");
+    return 3;
+  }
+
+  cals::JKReport rep;
+  try {
+    rep = cals::jk_cp_cals(T, refs, prm);
+  } catch (const std::exception &e) {
+    fprintf(stderr, "jk_cp_cals threw: %s\n", e.what());
+    return 2;
+  }
+  double worst = 0.0;
+  const int64_t jm[3] = {9, 21, 20};
+  for (dim_t k = 0; k < n_ktensors; k++)
+    for (dim_t i = 0; i < modes[0]; i++) {
+      cals::Tensor a = rep.results[k][i].to_regular().to_tensor();
+      // oracle replica without its (NaN) fiber row
+      const or_model &m = res[k * modes[0] + i];
+      std::vector<double> f0(9 * components);
+      for (dim_t c = 0; c < components; c++)
+        for (dim_t r = 0, o = 0; r < modes[0]; r++)
+          if (r != i) f0[(o++) + 9 * c] = m.factors[0][r + modes[0] * c];
+      double *facs[3] = {f0.data(), m.factors[1], m.factors[2]};
+      std::vector<double> b(a.get_n_elements());
+      or_to_tensor(facs, m.lambda, 3, jm, (int64_t)components, b.data());
+      double d = 0.0;
+      for (dim_t e = 0; e < a.get_n_elements(); e++) d += (a[e] - b[e]) * (a[e] - b[e]);
+      d = std::sqrt(d);
+      if (!(d <= worst)) worst = d;  // NaN propagates
+      // column order must agree too: compare factor 1 directly
+      double fd = 0.0;
+      for (dim_t e = 0; e < modes[1] * components; e++) {
+        const double x = rep.results[k][i].get_factor(1).get_data()[e] - m.factors[1][e];
+        fd += x * x;
+      }
+      if (!(std::sqrt(fd) <= 1e-8)) worst = (worst > std::sqrt(fd)) ? worst : std::sqrt(fd);
+    }
+  printf("jk_cp_cals C++ API: %zu models x %zu replicas, worst ||T_gpu - T_oracle|| / factor diff = %.3e\n",
+         (size_t)n_ktensors, (size_t)modes[0], worst);
+  return (worst <= 1e-9) ? 0 : 1;
+}

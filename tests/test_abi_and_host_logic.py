@@ -100,3 +100,26 @@ def test_compress_plan_packs_left(cc):
     assert cc.host_compress_plan([1, 1, 2, 0, 0]) == []
     assert cc.host_active_cols([0, 1, 1, 0, 0, 2, 0, 0]) == 6
     assert cc.host_active_cols([0, 0, 0, 0]) == 1  # adjust_edges never examines cell 0
+
+
+def test_lsap_solver_matches_scipy_and_bruteforce(oracle):
+    """The product's assignment solver (jk_permutation_adjustment, utils.cpp:83 calls SciPy's
+    rectangular_lsap in the reference) against scipy.optimize and the oracle's exhaustive search."""
+    from scipy.optimize import linear_sum_assignment
+    lib = ctypes.CDLL(os.path.join(ROOT, "cp-cals_amd", "libcals.so"))
+    orc = oracle.lib()
+    rng = np.random.default_rng(0)
+    for _ in range(300):
+        n = int(rng.integers(1, 9))
+        mx = bool(rng.integers(0, 2))
+        M = np.asfortranarray(rng.standard_normal((n, n)))
+        a = np.zeros(n, dtype=np.int64)
+        b = np.zeros(n, dtype=np.int64)
+        assert lib.cals_lsap_solve(n, M.ctypes.data_as(ctypes.c_void_p), int(mx), a.ctypes.data_as(ctypes.c_void_p)) == 0
+        assert orc.or_lsap_bruteforce(n, M.ctypes.data_as(ctypes.c_void_p), int(mx), b.ctypes.data_as(ctypes.c_void_p)) == 0
+        _, c = linear_sum_assignment(M, maximize=mx)
+        assert np.array_equal(a, c) and np.array_equal(b, c)
+    big = np.asfortranarray(rng.standard_normal((32, 32)))
+    a = np.zeros(32, dtype=np.int64)
+    assert lib.cals_lsap_solve(32, big.ctypes.data_as(ctypes.c_void_p), 1, a.ctypes.data_as(ctypes.c_void_p)) == 0
+    assert np.array_equal(a, linear_sum_assignment(big, maximize=True)[1])

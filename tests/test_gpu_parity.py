@@ -240,6 +240,25 @@ def test_cpp_api_cp_cals(arg):
     assert r.returncode == 0, r.stdout + r.stderr
 
 
+def test_cpp_api_jk_cp_cals():
+    """cals::jk_cp_cals (generate replicas, one cp_cals call, re-normalise, LSAP column matching) ==
+    the oracle's restatement (reference FunctionCorrectness, tests/cals/test_cals.cpp:299-362)."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "cpp", "test_jk_api")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    print(r.stdout, r.stderr)
+    assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_cli_driver_runs():
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cp-cals_amd", "examples", "driver")
+    import subprocess
+    r = subprocess.run([exe, "-t", "30-25-20", "-c", "1:4:3"], capture_output=True, text=True, timeout=300)
+    print(r.stdout, r.stderr)
+    assert r.returncode == 0 and "Speedup:" in r.stdout
+
+
 # ---- full-size properties (BASELINE configs 2 and 3): no oracle run, exact identities instead ----
 def test_full_size_c3_mttkrp_identities(cc, inputs):
     """300^3 fp64, 256 models ranks 1..20 (R = 2656): (1) columns of a model that is all-ones give
