@@ -453,29 +453,53 @@ int fetch_status(cals_hip_engine *e) {
 }
 
 // MultiKtensor::remove + Ktensor::detach (multi_ktensor.cpp:132-163, ktensor.cpp:127-135):
-// copy the model's columns back to the caller, zero them on the device, free the columns.
-int remove_model(cals_hip_engine *e, int64_t ticket) {
-  HostModel &m = e->models[ticket];
-  const int64_t r = m.rank;
-  for (int n = 0; n < e->n_modes; n++) {
-    const size_t bytes = sizeof(double) * (size_t)(e->modes[n] * r);
-    double *src = e->factor[n] + e->modes[n] * m.col;
-    HIPCHK(hipMemcpyAsync(m.factors[n], src, bytes, hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipMemsetAsync(src, 0, bytes, e->stream));
+// copy the models' columns back to the callers, zero them on the device, free the columns.
+int remove_models(cals_hip_engine *e, std::vector<int64_t> rm) {
+  if (rm.empty()) return CALS_HIP_OK;
+  // Ktensor::detach for every evicted model: models in adjacent columns come back as ONE D2H per
+  // mode (staging buffer, then scattered into the callers' storage) and one memset per mode.
+  std::sort(rm.begin(), rm.end(),
+            [&](int64_t a, int64_t b) { return e->models[a].col < e->models[b].col; });
+  std::vector<double> stage;
+  size_t k0 = 0;
+  while (k0 < rm.size()) {
+    size_t k1 = k0 + 1;
+    int64_t cols = e->models[rm[k0]].rank;
+    while (k1 < rm.size() && e->models[rm[k1]].col == e->models[rm[k0]].col + cols) {
+      cols += e->models[rm[k1]].rank;
+      k1++;
+    }
+    const int64_t col0 = e->models[rm[k0]].col;
+    for (int n = 0; n <= e->n_modes; n++) {  // n == n_modes: lambda
+      const int64_t rows = (n < e->n_modes) ? e->modes[n] : 1;
+      stage.resize((size_t)(rows * cols));
+      double *src = (n < e->n_modes) ? e->factor[n] + rows * col0 : e->lambda + col0;
+      HIPCHK(hipMemcpyAsync(stage.data(), src, sizeof(double) * stage.size(), hipMemcpyDeviceToHost,
+                            e->stream));
+      if (n < e->n_modes) HIPCHK(hipMemsetAsync(src, 0, sizeof(double) * stage.size(), e->stream));
+      HIPCHK(hipStreamSynchronize(e->stream));
+      size_t off = 0;
+      for (size_t k = k0; k < k1; k++) {
+        HostModel &m = e->models[rm[k]];
+        double *dst = (n < e->n_modes) ? m.factors[n] : m.lambda;
+        std::memcpy(dst, stage.data() + off, sizeof(double) * (size_t)(rows * m.rank));
+        off += (size_t)(rows * m.rank);
+      }
+    }
+    k0 = k1;
   }
-  HIPCHK(hipMemcpyAsync(m.lambda, e->lambda + m.col, sizeof(double) * (size_t)r,
-                        hipMemcpyDeviceToHost, e->stream));
-  HIPCHK(hipStreamSynchronize(e->stream));
-  m.st.iters = e->h_iters[m.slot];
-  m.st.approx_error = e->h_err[m.slot];
-  m.st.fit = e->h_fit[m.slot];
-  m.st.old_fit = e->h_old_fit[m.slot];
-  m.st.evicted = 1;
-  m.state = 2;
-  for (auto &c : e->occ)
-    if (c == m.id) c = 0;
-  e->free_slots.push_back(m.slot);
-  e->registry.erase(std::find(e->registry.begin(), e->registry.end(), ticket));
+  for (auto ticket : rm) {
+    HostModel &m = e->models[ticket];
+    m.st.iters = e->h_iters[m.slot];
+    m.st.approx_error = e->h_err[m.slot];
+    m.st.fit = e->h_fit[m.slot];
+    m.st.old_fit = e->h_old_fit[m.slot];
+    m.st.evicted = 1;
+    m.state = 2;
+    for (int64_t c = m.col; c < m.col + m.rank; c++) e->occ[(size_t)c] = 0;
+    e->free_slots.push_back(m.slot);
+    e->registry.erase(std::find(e->registry.begin(), e->registry.end(), ticket));
+  }
   e->slots_dirty = true;
   adjust_edges(e);
   return CALS_HIP_OK;
@@ -617,10 +641,8 @@ int evict(cals_hip_engine *e, int64_t *n_evicted) {
     for (auto t : e->registry)
       if (e->models[t].id == id && id > 0) rm.push_back(t);
   }
-  for (auto t : rm) {
-    int rc = remove_model(e, t);
-    if (rc) return rc;
-  }
+  int rc = remove_models(e, rm);
+  if (rc) return rc;
   if (n_evicted) *n_evicted = (int64_t)rm.size();
   return compress(e);
 }
