@@ -26,7 +26,11 @@ WORKLOADS = {
     "c3": ([300, 300, 300], 256, 1),   # BASELINE config 3 (default)
     "c2": ([100, 100, 100], 64, 0),    # BASELINE config 2
     "c1": ([20, 20, 20], 4, 0),        # BASELINE config 1 (plumbing)
+    "c4": ([299, 301, 41], 512, 0),    # BASELINE config 4: eemdata-shaped, fp32 storage + fp32 MFMA
+    "c4f64": ([299, 301, 41], 512, 0),  # config 4's shape and model count, in fp64
 }
+WORKLOAD_DTYPE = {"c4": "f32"}
+PEAK_FP32_MFMA_TFLOPS = 157.3  # dense FP32 matrix peak (v_mfma_f32_16x16x4_f32: 256 flop/cycle/CU x4 SIMD)
 PEAK_FP64_MFMA_TFLOPS = 78.6  # MI355X dense FP64 matrix peak (datasheet; 256 CU x 4 SIMD x 2.4 GHz
 #                               x 2048 flop / 64 cycles).  tools/mfma_f64_peak measures 77.7 on the box.
 
@@ -114,7 +118,9 @@ def main():
     X = inputs.tensor(modes, seed=0)        # replicated: every rank generates the same X
     base = inputs.model_factors(modes, ranks, seed=1 + rank)
 
-    eng = cc.Engine(modes, R, device=local_rank)
+    dtype = WORKLOAD_DTYPE.get(args.workload, "f64")
+    peak = PEAK_FP32_MFMA_TFLOPS if dtype == "f32" else PEAK_FP64_MFMA_TFLOPS
+    eng = cc.Engine(modes, R, device=local_rank, dtype=dtype)
     eng.set_tensor(X)
     eng.set_params(cc.default_params(max_iterations=10 ** 9, force_max_iter=1, line_search=ls,
                                      line_search_interval=5, line_search_step=0.0))
@@ -153,17 +159,19 @@ def main():
             "metric": "ALS iterations/sec (all concurrent models)",
             "value": round(value, 3), "unit": "ALS it/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(t_max / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype,
             "data": "synthetic",
-            "config": {"workload": "%s fp64 dense tensor, %d concurrent CP models per GPU, ranks 1..20 "
+            "config": {"workload": "%s %s dense tensor, %d concurrent CP models per GPU, ranks 1..20 "
                                    "(R=%d columns), line search %s; one step = one ALS sweep of a GPU's "
                                    "model shard; value = sweeps by all %d GPU(s) / max time" % (
-                                       "x".join(map(str, modes)), k_models, R, "on" if ls else "off", world),
+                                       "x".join(map(str, modes)), "fp32" if dtype == "f32" else "fp64",
+                                       k_models, R, "on" if ls else "off", world),
                        "name": args.workload, "models_per_gpu": k_models, "total_models": k_models * world,
                        "sharding": "model m -> GPU m mod N, X replicated, no data-path collective"},
-            "roofline": {"bound": "mfma", "kernel": "mttkrp_kernel (fused MTTKRP, v_mfma_f64_16x16x4_f64)",
-                         "achieved": round(achieved, 3), "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_FP64_MFMA_TFLOPS, 4), "traffic": traffic,
+            "roofline": {"bound": "mfma", "kernel": "mttkrp3_kernel (fused MTTKRP, v_mfma_%s)" % (
+                             "f32_16x16x4_f32" if dtype == "f32" else "f64_16x16x4_f64"),
+                         "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",
+                         "frac": round(achieved / peak, 4), "traffic": traffic,
                          "flops_per_launch": flops_per_launch, "avg_launch_ms": round(avg_ms, 4),
                          "launches": ks.mttkrp_launches,
                          "other_kernels_ms_per_step": round((ks.update_ms + ks.other_ms) / args.steps, 4)},

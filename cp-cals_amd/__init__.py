@@ -54,6 +54,8 @@ class KernelStats(C.Structure):
     ]
 
 
+DTYPES = {"f64": 0, "f32": 1}  # CALS_HIP_F64 / CALS_HIP_F32
+
 EXPORTS = [
     "cals_hip_default_params", "cals_hip_create", "cals_hip_destroy", "cals_hip_last_error",
     "cals_hip_set_tensor", "cals_hip_set_params", "cals_hip_enqueue", "cals_hip_run",
@@ -63,6 +65,7 @@ EXPORTS = [
     "cals_hip_debug_get_lambda", "cals_hip_debug_get_gramian", "cals_hip_debug_model_status",
     "cals_hip_debug_get_norms", "cals_hip_set_profiling", "cals_hip_get_kernel_stats",
     "cals_hip_reset_kernel_stats", "cals_hip_stream", "cals_hip_device_count",
+    "cals_hip_create_ex", "cals_hip_dtype", "cals_hip_set_tensor_f32",
     "cals_hip_debug_clock", "cals_hip_host_first_fit", "cals_hip_host_compress_plan", "cals_hip_host_active_cols",
 ]
 
@@ -80,6 +83,9 @@ def load_library():
     lib = C.CDLL(LIB_PATH)
     vp, i64, dp = C.c_void_p, C.c_int64, C.POINTER(C.c_double)
     lib.cals_hip_create.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(i64), i64, C.c_int]
+    lib.cals_hip_create_ex.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(i64), i64, C.c_int, C.c_int]
+    lib.cals_hip_dtype.argtypes = [vp]
+    lib.cals_hip_set_tensor_f32.argtypes = [vp, C.POINTER(C.c_float)]
     lib.cals_hip_destroy.argtypes = [vp]
     lib.cals_hip_last_error.argtypes = [vp]
     lib.cals_hip_last_error.restype = C.c_char_p
@@ -170,12 +176,18 @@ class Model:
 class Engine:
     """One CALS engine on one GPU (cals_hip_engine)."""
 
-    def __init__(self, modes, buffer_size, device=0):
+    def __init__(self, modes, buffer_size, device=0, dtype="f64"):
+        """dtype: "f64" (reference arithmetic) or "f32" (fp32 storage + fp32 MFMA MTTKRP,
+        BASELINE config 4); factors cross the boundary as float64 either way."""
         self.lib = load_library()
         self.modes = [int(m) for m in modes]
         self.h = C.c_void_p()
+        if dtype not in DTYPES:
+            raise ValueError("dtype must be one of %s" % sorted(DTYPES))
+        self.dtype = dtype
         arr = (C.c_int64 * len(self.modes))(*self.modes)
-        rc = self.lib.cals_hip_create(C.byref(self.h), len(self.modes), arr, int(buffer_size), int(device))
+        rc = self.lib.cals_hip_create_ex(C.byref(self.h), len(self.modes), arr, int(buffer_size),
+                                         int(device), DTYPES[dtype])
         if rc != OK:
             msg = self.lib.cals_hip_last_error(self.h).decode() if self.h else "create failed"
             if self.h:
@@ -200,8 +212,13 @@ class Engine:
             pass
 
     def set_tensor(self, X):
+        X = np.asarray(X)
+        assert X.size == int(np.prod(self.modes))
+        if X.dtype == np.float32:
+            Xf = np.ascontiguousarray(X.ravel())
+            self._chk(self.lib.cals_hip_set_tensor_f32(self.h, Xf.ctypes.data_as(C.POINTER(C.c_float))))
+            return
         Xf = np.ascontiguousarray(np.asarray(X, dtype=np.float64).ravel())
-        assert Xf.size == int(np.prod(self.modes))
         self._chk(self.lib.cals_hip_set_tensor(self.h, _dp(Xf)))
 
     def set_params(self, params):
@@ -253,6 +270,10 @@ class Engine:
     @property
     def models_in_flight(self):
         return self.lib.cals_hip_models_in_flight(self.h)
+
+    @property
+    def queue_size(self):
+        return int(self.lib.cals_hip_queue_size(self.h))
 
     def debug_mttkrp(self, mode):
         R = self.active_cols

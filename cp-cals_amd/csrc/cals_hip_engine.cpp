@@ -41,7 +41,7 @@ struct ModeLayout {
   std::vector<int> s_modes;
   int A = 0, Ap = 0, Mp = 0;
   long long S = 1;
-  double *Xp = nullptr;
+  void *Xp = nullptr;  // storage dtype of the engine
   int MT = 0, m_blocks = 1, ldPart = 0;        // v1 tiling (8 waves, one workgroup per CU)
   int MT2 = 0, m_blocks2 = 1, k_big2 = 0;      // v2 tiling (two 4-wave workgroups per CU)
 };
@@ -75,15 +75,17 @@ struct cals_hip_engine {
   std::vector<double> jk_norms;
   ModeLayout lay[CALS_HIP_MAX_MODES];
 
-  double *factor[CALS_HIP_MAX_MODES] = {nullptr};
-  double *prev[CALS_HIP_MAX_MODES] = {nullptr};
-  double *backup[CALS_HIP_MAX_MODES] = {nullptr};
+  int dtype = CALS_F64;  // storage type of X copies, multi-factors, partials (compute follows it)
+  size_t es = sizeof(double);
+  void *factor[CALS_HIP_MAX_MODES] = {nullptr};
+  void *prev[CALS_HIP_MAX_MODES] = {nullptr};
+  void *backup[CALS_HIP_MAX_MODES] = {nullptr};
   double *gram[CALS_HIP_MAX_MODES] = {nullptr};
   double *lambda = nullptr, *prev_lambda = nullptr, *backup_lambda = nullptr;
   bool ls_allocated = false;
-  double *partial = nullptr;
+  void *partial = nullptr;
   size_t partial_elems = 0;
-  double *krp_ws = nullptr;
+  void *krp_ws = nullptr;
   size_t krp_elems = 0;
   unsigned long long *dbg_clock = nullptr;  // CALS_MTTKRP_CLOCK=1: in-kernel clock stamps
 
@@ -145,6 +147,16 @@ int dev_alloc(cals_hip_engine *e, T **p, size_t n) {
   HIPCHK(hipMalloc((void **)p, std::max<size_t>(n, 1) * sizeof(T)));
   HIPCHK(hipMemsetAsync(*p, 0, std::max<size_t>(n, 1) * sizeof(T), e->stream));
   return CALS_HIP_OK;
+}
+
+// zero-initialised buffer of n storage elements (double | float)
+int dev_alloc_elems(cals_hip_engine *e, void **p, size_t n) {
+  HIPCHK(hipMalloc(p, std::max<size_t>(n, 1) * e->es));
+  HIPCHK(hipMemsetAsync(*p, 0, std::max<size_t>(n, 1) * e->es, e->stream));
+  return CALS_HIP_OK;
+}
+inline void *elem_ptr(const cals_hip_engine *e, void *base, long long idx) {
+  return (char *)base + (size_t)idx * e->es;
 }
 
 // MultiKtensor::adjust_edges, src/multi_ktensor.cpp:165-186 (cell 0 is never examined)
@@ -254,8 +266,8 @@ int alloc_ls(cals_hip_engine *e) {
   if (e->ls_allocated) return CALS_HIP_OK;
   for (int n = 0; n < e->n_modes; n++) {
     int rc;
-    if ((rc = dev_alloc(e, &e->prev[n], (size_t)(e->modes[n] * e->buffer)))) return rc;
-    if ((rc = dev_alloc(e, &e->backup[n], (size_t)(e->modes[n] * e->buffer)))) return rc;
+    if ((rc = dev_alloc_elems(e, &e->prev[n], (size_t)(e->modes[n] * e->buffer)))) return rc;
+    if ((rc = dev_alloc_elems(e, &e->backup[n], (size_t)(e->modes[n] * e->buffer)))) return rc;
   }
   int rc;
   if ((rc = dev_alloc(e, &e->prev_lambda, (size_t)e->buffer))) return rc;
@@ -285,7 +297,7 @@ Geo geometry(const cals_hip_engine *e, int mode, int64_t R) {
 int launch_mttkrp(cals_hip_engine *e, int mode, int64_t R, Geo *geo_out) {
   const ModeLayout &L = e->lay[mode];
   const Geo g = geometry(e, mode, R);
-  const double *Q;
+  const void *Q;
   long long ldQ;
   if (L.s_modes.size() == 1) {
     Q = e->factor[L.s_modes[0]];
@@ -301,6 +313,7 @@ int launch_mttkrp(cals_hip_engine *e, int mode, int64_t R, Geo *geo_out) {
     k.S = L.S;
     k.R = (int)R;
     k.Q = e->krp_ws;
+    k.dtype = e->dtype;
     const int pk = prof_begin(e, 2, 0);
     HIPCHK(krp_launch(k, e->stream));
     prof_end(e, pk);
@@ -314,6 +327,7 @@ int launch_mttkrp(cals_hip_engine *e, int mode, int64_t R, Geo *geo_out) {
   a.Q = Q;
   a.ldQ = ldQ;
   a.partial = e->partial;
+  a.dtype = e->dtype;
   a.S = L.S;
   a.Mp = L.Mp;
   a.Ap = L.Ap;
@@ -363,6 +377,7 @@ LsArgs make_ls_args(cals_hip_engine *e) {
     a.I[n] = (int)e->modes[n];
     a.gram[n] = e->gram[n];
   }
+  a.dtype = e->dtype;
   a.lambda = e->lambda;
   a.prev_lambda = e->prev_lambda;
   a.backup_lambda = e->backup_lambda;
@@ -395,6 +410,7 @@ int sweep_once(cals_hip_engine *e, bool evict_enabled) {
     u.n_slots = ns;
     u.mt = e->mt;
     u.factor = e->factor[n];
+    u.dtype = e->dtype;
     u.I = (int)e->modes[n];
     u.partial = e->partial;
     u.NB = g.NB;
@@ -409,7 +425,7 @@ int sweep_once(cals_hip_engine *e, bool evict_enabled) {
     u.jk_norms = e->d_jk_norms;
     const int pk = prof_begin(e, 1, 0);
     HIPCHK(reduce_partials_launch(e->partial, g.T, e->lay[n].ldPart, (int)e->modes[n], (int)R,
-                                  e->factor[n], e->stream));
+                                  e->factor[n], e->dtype, e->stream));
     HIPCHK(update_launch(u, CALS_RMAX, e->stream));
     prof_end(e, pk);
   }
@@ -461,6 +477,7 @@ int remove_models(cals_hip_engine *e, std::vector<int64_t> rm) {
   std::sort(rm.begin(), rm.end(),
             [&](int64_t a, int64_t b) { return e->models[a].col < e->models[b].col; });
   std::vector<double> stage;
+  std::vector<float> stage_f;
   size_t k0 = 0;
   while (k0 < rm.size()) {
     size_t k1 = k0 + 1;
@@ -473,11 +490,16 @@ int remove_models(cals_hip_engine *e, std::vector<int64_t> rm) {
     for (int n = 0; n <= e->n_modes; n++) {  // n == n_modes: lambda
       const int64_t rows = (n < e->n_modes) ? e->modes[n] : 1;
       stage.resize((size_t)(rows * cols));
-      double *src = (n < e->n_modes) ? e->factor[n] + rows * col0 : e->lambda + col0;
-      HIPCHK(hipMemcpyAsync(stage.data(), src, sizeof(double) * stage.size(), hipMemcpyDeviceToHost,
-                            e->stream));
-      if (n < e->n_modes) HIPCHK(hipMemsetAsync(src, 0, sizeof(double) * stage.size(), e->stream));
+      const bool f32 = (n < e->n_modes) && e->dtype == CALS_F32;
+      if (f32) stage_f.resize(stage.size());
+      void *src = (n < e->n_modes) ? elem_ptr(e, e->factor[n], rows * col0) : (void *)(e->lambda + col0);
+      const size_t bytes = stage.size() * (f32 ? sizeof(float) : sizeof(double));
+      HIPCHK(hipMemcpyAsync(f32 ? (void *)stage_f.data() : (void *)stage.data(), src, bytes,
+                            hipMemcpyDeviceToHost, e->stream));
+      if (n < e->n_modes) HIPCHK(hipMemsetAsync(src, 0, bytes, e->stream));
       HIPCHK(hipStreamSynchronize(e->stream));
+      if (f32)
+        for (size_t i = 0; i < stage.size(); i++) stage[i] = (double)stage_f[i];
       size_t off = 0;
       for (size_t k = k0; k < k1; k++) {
         HostModel &m = e->models[rm[k]];
@@ -520,17 +542,17 @@ int compress(cals_hip_engine *e) {
     if (!m) return fail(e, CALS_HIP_ERR_STATE, "internal: compress lost a model");
     const int64_t off = rq.second, r = m->rank, col = m->col;
     for (int n = 0; n < e->n_modes; n++) {
-      HIPCHK(move_columns_launch(e->factor[n], e->modes[n], col, r, off, e->stream));
-      HIPCHK(move_columns_launch(e->gram[n], CALS_RMAX, col, r, off, e->stream));
+      HIPCHK(move_columns_launch(e->factor[n], e->dtype, e->modes[n], col, r, off, e->stream));
+      HIPCHK(move_columns_launch(e->gram[n], CALS_F64, CALS_RMAX, col, r, off, e->stream));
       if (e->ls_allocated) {
-        HIPCHK(move_columns_launch(e->prev[n], e->modes[n], col, r, off, e->stream));
-        HIPCHK(move_columns_launch(e->backup[n], e->modes[n], col, r, off, e->stream));
+        HIPCHK(move_columns_launch(e->prev[n], e->dtype, e->modes[n], col, r, off, e->stream));
+        HIPCHK(move_columns_launch(e->backup[n], e->dtype, e->modes[n], col, r, off, e->stream));
       }
     }
-    HIPCHK(move_columns_launch(e->lambda, 1, col, r, off, e->stream));
+    HIPCHK(move_columns_launch(e->lambda, CALS_F64, 1, col, r, off, e->stream));
     if (e->ls_allocated) {
-      HIPCHK(move_columns_launch(e->prev_lambda, 1, col, r, off, e->stream));
-      HIPCHK(move_columns_launch(e->backup_lambda, 1, col, r, off, e->stream));
+      HIPCHK(move_columns_launch(e->prev_lambda, CALS_F64, 1, col, r, off, e->stream));
+      HIPCHK(move_columns_launch(e->backup_lambda, CALS_F64, 1, col, r, off, e->stream));
     }
     for (int64_t i = col; i < col + r; i++) std::swap(e->occ[i - off], e->occ[i]);
     m->col -= off;
@@ -576,6 +598,7 @@ int admit(cals_hip_engine *e, int64_t *n_admitted) {
     // back sit in adjacent columns, so each run goes up as ONE H2D per mode from a staging buffer.
     size_t k0 = 0;
     std::vector<double> stage;
+    std::vector<float> stage_f;
     while (k0 < admitted.size()) {
       size_t k1 = k0 + 1;
       int64_t cols = e->models[admitted[k0]].rank;
@@ -595,8 +618,14 @@ int admit(cals_hip_engine *e, int64_t *n_admitted) {
           std::memcpy(stage.data() + off, src, sizeof(double) * (size_t)(rows * m.rank));
           off += (size_t)(rows * m.rank);
         }
-        double *dst = (n < e->n_modes) ? e->factor[n] + rows * col0 : e->lambda + col0;
-        HIPCHK(hipMemcpyAsync(dst, stage.data(), sizeof(double) * stage.size(),
+        const bool f32 = (n < e->n_modes) && e->dtype == CALS_F32;
+        if (f32) {  // fp32 storage: the callers' fp64 factors are rounded once, on admission
+          stage_f.resize(stage.size());
+          for (size_t i = 0; i < stage.size(); i++) stage_f[i] = (float)stage[i];
+        }
+        void *dst = (n < e->n_modes) ? elem_ptr(e, e->factor[n], rows * col0) : (void *)(e->lambda + col0);
+        HIPCHK(hipMemcpyAsync(dst, f32 ? (const void *)stage_f.data() : (const void *)stage.data(),
+                              stage.size() * (f32 ? sizeof(float) : sizeof(double)),
                               hipMemcpyHostToDevice, e->stream));
         HIPCHK(hipStreamSynchronize(e->stream));  // stage is reused
       }
@@ -621,6 +650,7 @@ int admit(cals_hip_engine *e, int64_t *n_admitted) {
       g.gram[n] = e->gram[n];
     }
     g.n_modes = e->n_modes;
+    g.dtype = e->dtype;
     HIPCHK(gram_init_launch(g, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     HIPCHK(hipFree(d_desc));
@@ -673,10 +703,19 @@ int cals_hip_device_count(void) {
 
 int cals_hip_create(cals_hip_engine **out, int n_modes, const int64_t *modes, int64_t buffer_size,
                     int device) {
+  return cals_hip_create_ex(out, n_modes, modes, buffer_size, device, CALS_HIP_F64);
+}
+
+int cals_hip_create_ex(cals_hip_engine **out, int n_modes, const int64_t *modes,
+                       int64_t buffer_size, int device, int dtype) {
   if (!out) return CALS_HIP_ERR_ARG;
   *out = nullptr;
   cals_hip_engine *e = new cals_hip_engine();
   *out = e;  // returned even on failure so the caller can read last_error, then destroy
+  if (dtype != CALS_HIP_F64 && dtype != CALS_HIP_F32)
+    return fail(e, CALS_HIP_ERR_ARG, "dtype must be CALS_HIP_F64 or CALS_HIP_F32");
+  e->dtype = (dtype == CALS_HIP_F32) ? CALS_F32 : CALS_F64;
+  e->es = (dtype == CALS_HIP_F32) ? sizeof(float) : sizeof(double);
   if (n_modes < 3 || n_modes > CALS_HIP_MAX_MODES || !modes || buffer_size < 1)
     return fail(e, CALS_HIP_ERR_ARG, "need 3 <= n_modes <= 8, modes, buffer_size >= 1");
   int ndev = 0;
@@ -736,7 +775,7 @@ int cals_hip_create(cals_hip_engine **out, int n_modes, const int64_t *modes, in
   }
   int rc;
   for (int n = 0; n < n_modes; n++) {
-    if ((rc = dev_alloc(e, &e->factor[n], (size_t)(modes[n] * buffer_size)))) return rc;
+    if ((rc = dev_alloc_elems(e, &e->factor[n], (size_t)(modes[n] * buffer_size)))) return rc;
     if ((rc = dev_alloc(e, &e->gram[n], (size_t)(CALS_RMAX * buffer_size)))) return rc;
   }
   if ((rc = dev_alloc(e, &e->lambda, (size_t)buffer_size))) return rc;
@@ -751,11 +790,12 @@ int cals_hip_create(cals_hip_engine **out, int n_modes, const int64_t *modes, in
     const int v = atoi(k);
     e->mttkrp_kernel = (v >= 2 && v <= 4) ? v : 1;
   }
+  if (e->dtype == CALS_F32) e->mttkrp_kernel = 4;  // the fp32 MTTKRP exists in the v3 schedule only
   (void)part_rows_max;
-  if ((rc = dev_alloc(e, &e->partial, e->partial_elems))) return rc;
+  if ((rc = dev_alloc_elems(e, &e->partial, e->partial_elems))) return rc;
   if (krp_max) {
     e->krp_elems = krp_max;
-    if ((rc = dev_alloc(e, &e->krp_ws, krp_max))) return rc;
+    if ((rc = dev_alloc_elems(e, &e->krp_ws, krp_max))) return rc;
   }
   e->max_slots = (int)std::min<int64_t>(buffer_size, 1 << 20);
   const size_t ms = (size_t)e->max_slots;
@@ -836,15 +876,16 @@ int cals_hip_destroy(cals_hip_engine *e) {
 
 const char *cals_hip_last_error(const cals_hip_engine *e) { return e ? e->err.c_str() : "null engine"; }
 
-int cals_hip_set_tensor(cals_hip_engine *e, const double *X_host) {
+namespace {
+int set_tensor_impl(cals_hip_engine *e, const void *X_host, int src_dtype) {
   if (!e || !X_host) return CALS_HIP_ERR_ARG;
   if (!e->stream) return fail(e, CALS_HIP_ERR_STATE, "engine not initialised");
   long long total = 1;
   for (int n = 0; n < e->n_modes; n++) total *= e->modes[n];
-  double *dX = nullptr;
-  HIPCHK(hipMalloc((void **)&dX, (size_t)total * sizeof(double)));
-  HIPCHK(hipMemcpyAsync(dX, X_host, (size_t)total * sizeof(double), hipMemcpyHostToDevice,
-                        e->stream));
+  const size_t src_es = (src_dtype == CALS_F32) ? sizeof(float) : sizeof(double);
+  void *dX = nullptr;
+  HIPCHK(hipMalloc(&dX, (size_t)total * src_es));
+  HIPCHK(hipMemcpyAsync(dX, X_host, (size_t)total * src_es, hipMemcpyHostToDevice, e->stream));
   int dims[CALS_HIP_MAX_MODES];
   for (int n = 0; n < e->n_modes; n++) dims[n] = (int)e->modes[n];
   for (int n = 0; n < e->n_modes; n++) {
@@ -854,8 +895,9 @@ int cals_hip_set_tensor(cals_hip_engine *e, const double *X_host) {
       L.Xp = nullptr;
     }
     const size_t elems = (size_t)L.Mp * (size_t)L.Ap * (size_t)L.S;
-    HIPCHK(hipMalloc((void **)&L.Xp, elems * sizeof(double)));
-    HIPCHK(permute_pad_launch(dX, e->n_modes, dims, n, L.a_mode, L.Mp, L.Ap, L.Xp, L.S, e->stream));
+    HIPCHK(hipMalloc((void **)&L.Xp, elems * e->es));
+    HIPCHK(permute_pad_launch(dX, src_dtype, e->n_modes, dims, n, L.a_mode, L.Mp, L.Ap, L.Xp,
+                              e->dtype, L.S, e->stream));
   }
   // ||X|| and the jackknife norms from the mode-0 slice sums of squares
   const long long I = e->modes[0], cols = total / I;
@@ -863,7 +905,7 @@ int cals_hip_set_tensor(cals_hip_engine *e, const double *X_host) {
   double *d_part = nullptr, *d_ss = nullptr;
   HIPCHK(hipMalloc((void **)&d_part, (size_t)n_part * (size_t)I * sizeof(double)));
   HIPCHK(hipMalloc((void **)&d_ss, (size_t)I * sizeof(double)));
-  HIPCHK(slice_sumsq_launch(dX, I, cols, d_part, n_part, d_ss, e->stream));
+  HIPCHK(slice_sumsq_launch(dX, src_dtype, I, cols, d_part, n_part, d_ss, e->stream));
   std::vector<double> ss((size_t)I);
   HIPCHK(hipMemcpyAsync(ss.data(), d_ss, (size_t)I * sizeof(double), hipMemcpyDeviceToHost,
                         e->stream));
@@ -881,6 +923,19 @@ int cals_hip_set_tensor(cals_hip_engine *e, const double *X_host) {
   HIPCHK(hipFree(dX));
   e->has_tensor = true;
   return CALS_HIP_OK;
+}
+}  // namespace
+
+int cals_hip_set_tensor(cals_hip_engine *e, const double *X_host) {
+  return set_tensor_impl(e, X_host, CALS_F64);
+}
+
+int cals_hip_set_tensor_f32(cals_hip_engine *e, const float *X_host) {
+  return set_tensor_impl(e, X_host, CALS_F32);
+}
+
+int cals_hip_dtype(const cals_hip_engine *e) {
+  return (e && e->dtype == CALS_F32) ? CALS_HIP_F32 : CALS_HIP_F64;
 }
 
 int cals_hip_set_params(cals_hip_engine *e, const cals_hip_params *p) {
@@ -1011,9 +1066,17 @@ int cals_hip_debug_mttkrp(cals_hip_engine *e, int mode, double *G_host) {
   const ModeLayout &L = e->lay[mode];
   const size_t tile = (size_t)L.ldPart * CALS_BN;
   std::vector<double> part((size_t)g.NB * g.T * tile);
-  HIPCHK(hipMemcpyAsync(part.data(), e->partial, part.size() * sizeof(double),
-                        hipMemcpyDeviceToHost, e->stream));
-  HIPCHK(hipStreamSynchronize(e->stream));
+  if (e->dtype == CALS_F32) {
+    std::vector<float> pf(part.size());
+    HIPCHK(hipMemcpyAsync(pf.data(), e->partial, pf.size() * sizeof(float), hipMemcpyDeviceToHost,
+                          e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    for (size_t i = 0; i < pf.size(); i++) part[i] = (double)pf[i];
+  } else {
+    HIPCHK(hipMemcpyAsync(part.data(), e->partial, part.size() * sizeof(double),
+                          hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+  }
   const int64_t I = e->modes[mode];
   for (int64_t c = 0; c < R; c++)
     for (int64_t i = 0; i < I; i++) {
@@ -1027,8 +1090,17 @@ int cals_hip_debug_mttkrp(cals_hip_engine *e, int mode, double *G_host) {
 
 int cals_hip_debug_get_factor(cals_hip_engine *e, int mode, double *host) {
   if (!e || !host || mode < 0 || mode >= e->n_modes) return CALS_HIP_ERR_ARG;
-  HIPCHK(hipMemcpyAsync(host, e->factor[mode], sizeof(double) * (size_t)(e->modes[mode] * e->end),
-                        hipMemcpyDeviceToHost, e->stream));
+  const size_t n = (size_t)(e->modes[mode] * e->end);
+  if (e->dtype == CALS_F32) {
+    std::vector<float> hf(n);
+    HIPCHK(hipMemcpyAsync(hf.data(), e->factor[mode], sizeof(float) * n, hipMemcpyDeviceToHost,
+                          e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    for (size_t i = 0; i < n; i++) host[i] = (double)hf[i];
+    return CALS_HIP_OK;
+  }
+  HIPCHK(hipMemcpyAsync(host, e->factor[mode], sizeof(double) * n, hipMemcpyDeviceToHost,
+                        e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
   return CALS_HIP_OK;
 }

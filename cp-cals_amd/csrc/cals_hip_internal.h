@@ -14,11 +14,15 @@ namespace calship {
 // ---------------------------------------------------------------------------------------------
 // MTTKRP  G[m,c] = sum_{a,s} Xp[m,a,s] * P[a,c] * Q[s,c]     (DESIGN.md "MTTKRP kernel")
 // ---------------------------------------------------------------------------------------------
+enum { CALS_F64 = 0, CALS_F32 = 1 };  // storage type of X, the multi-factors and the partials
+
 struct MttkrpArgs {
-  const double *Xp;  // permuted, zero-padded tensor copy for this mode: [Mp][Ap][S], m fastest
-  const double *P;   // factor of the inner ("a") mode, A x R, ld = ldP
-  const double *Q;   // factor (or Khatri-Rao of the factors) of the streamed modes, S x R, ld = ldQ
-  double *partial;   // split partial results: [NB*T] tiles of ldPart x CALS_BN, col-major
+  // element type = dtype (double | float); v1/v2 kernels are fp64 only
+  const void *Xp;    // permuted, zero-padded tensor copy for this mode: [Mp][Ap][S], m fastest
+  const void *P;     // factor of the inner ("a") mode, A x R, ld = ldP
+  const void *Q;     // factor (or Khatri-Rao of the factors) of the streamed modes, S x R, ld = ldQ
+  void *partial;     // split partial results: [NB*T] tiles of ldPart x CALS_BN, col-major
+  int dtype;
   long long S, ldP, ldQ;
   int Mp, Ap, A;
   int R;             // active columns
@@ -47,13 +51,14 @@ hipError_t mttkrp3_launch(int MT, int m_blocks, const MttkrpArgs &a, hipStream_t
 
 // Q[s,c] for N > 3: Khatri-Rao of the streamed modes' factors (first streamed mode fastest)
 struct KrpArgs {
-  const double *F[CALS_MAX_MODES];
+  const void *F[CALS_MAX_MODES];  // element type = dtype
   long long ld[CALS_MAX_MODES];
   int dims[CALS_MAX_MODES];
   int n;         // number of streamed modes
   long long S;   // prod(dims)
   int R;
-  double *Q;     // S x R, ld = S
+  void *Q;       // S x R, ld = S
+  int dtype;
 };
 hipError_t krp_launch(const KrpArgs &a, hipStream_t st);
 
@@ -80,9 +85,10 @@ struct UpdateArgs {
   const int *slots;    // active slots, one wave each
   int n_slots;
   ModelTable mt;
-  double *factor;      // multi-factor of this mode, I x buffer, ld = I
+  void *factor;        // multi-factor of this mode (element type = dtype), I x buffer, ld = I
+  int dtype;
   int I;
-  const double *partial;  // MTTKRP partial tiles
+  const void *partial;  // MTTKRP partial tiles (dtype)
   int NB, T, ldPart;
   double *gram[CALS_MAX_MODES];  // column-indexed Gramian stores: CALS_RMAX x buffer, ld CALS_RMAX
   double *lambda;      // per column
@@ -93,8 +99,8 @@ struct UpdateArgs {
 };
 hipError_t update_launch(const UpdateArgs &a, int rmax_needed, hipStream_t st);
 // deterministic reduction of the MTTKRP split partials into the multi-factor of the mode
-hipError_t reduce_partials_launch(const double *partial, int T, int ldPart, int I, int R,
-                                  double *factor, hipStream_t st);
+hipError_t reduce_partials_launch(const void *partial, int T, int ldPart, int I, int R,
+                                  void *factor, int dtype, hipStream_t st);
 // desc: n x {slot, col, rank, jk_mode, jk_fiber}
 hipError_t init_slots_launch(const int *desc, int n, const ModelTable &mt, hipStream_t st);
 
@@ -103,10 +109,11 @@ struct GramInitArgs {
   const int *slots;
   int n_slots;
   ModelTable mt;
-  const double *factor[CALS_MAX_MODES];
+  const void *factor[CALS_MAX_MODES];
   int I[CALS_MAX_MODES];
   double *gram[CALS_MAX_MODES];
   int n_modes;
+  int dtype;
 };
 hipError_t gram_init_launch(const GramInitArgs &a, hipStream_t st);
 
@@ -115,9 +122,10 @@ struct LsArgs {
   const int *slots;
   int n_slots;
   ModelTable mt;
-  double *factor[CALS_MAX_MODES];
-  double *prev[CALS_MAX_MODES];
-  double *backup[CALS_MAX_MODES];
+  void *factor[CALS_MAX_MODES];  // element type = dtype
+  void *prev[CALS_MAX_MODES];
+  void *backup[CALS_MAX_MODES];
+  int dtype;
   int I[CALS_MAX_MODES];
   double *gram[CALS_MAX_MODES];
   double *lambda, *prev_lambda, *backup_lambda;
@@ -141,14 +149,15 @@ struct FinishArgs {
 hipError_t finish_launch(const FinishArgs &a, hipStream_t st);   // cals.cpp:336-354
 
 // set-up kernels
-hipError_t permute_pad_launch(const double *X, int n_modes, const int *dims, int m_mode,
-                              int a_mode, int Mp, int Ap, double *Xp, long long S,
+// X: src_dtype elements (as uploaded), Xp: dst_dtype elements
+hipError_t permute_pad_launch(const void *X, int src_dtype, int n_modes, const int *dims, int m_mode,
+                              int a_mode, int Mp, int Ap, void *Xp, int dst_dtype, long long S,
                               hipStream_t st);
-hipError_t slice_sumsq_launch(const double *X, long long I, long long cols, double *partial,
-                              int n_part, double *ss_out, hipStream_t st);
+hipError_t slice_sumsq_launch(const void *X, int src_dtype, long long I, long long cols,
+                              double *partial, int n_part, double *ss_out, hipStream_t st);
 // move `ncols` columns of an (rows x *) col-major buffer left by `off` columns (compress)
-hipError_t move_columns_launch(double *buf, long long rows, long long src_col, long long ncols,
-                               long long off, hipStream_t st);
+hipError_t move_columns_launch(void *buf, int dtype, long long rows, long long src_col,
+                               long long ncols, long long off, hipStream_t st);
 
 }  // namespace calship
 #endif

@@ -19,6 +19,7 @@
 #include "cals_hip_internal.h"
 
 #include <cfloat>
+#include <type_traits>
 
 namespace calship {
 
@@ -33,7 +34,8 @@ __device__ __forceinline__ double wave_sum(double v) {
 // Gamma = P^T P for the I x r panel (ld) with r <= 32, on the f64 matrix cores: each k-step covers 4
 // rows; lane (lcol, krow) supplies P[i0+krow, lcol] as both the A and the B operand.
 // Written to g (ld = CALS_RMAX).  Must be called by a whole wave with EXEC all ones.
-__device__ __forceinline__ void gramian_wave(const double *panel, int rows, long long ld, int r,
+template <typename T>
+__device__ __forceinline__ void gramian_wave(const T *panel, int rows, long long ld, int r,
                                              double *g, int lane) {
   const int krow = lane >> 4, lcol = lane & 15;
   const bool two = r > 16;
@@ -42,10 +44,10 @@ __device__ __forceinline__ void gramian_wave(const double *panel, int rows, long
   for (int i0 = 0; i0 < rows; i0 += 4) {
     const int i = i0 + krow;
     const bool rok = i < rows;
-    const double p0 = (rok && c0ok) ? panel[i + ld * lcol] : 0.0;
+    const double p0 = (rok && c0ok) ? (double)panel[i + ld * lcol] : 0.0;
     a00 = __builtin_amdgcn_mfma_f64_16x16x4f64(p0, p0, a00, 0, 0, 0);
     if (two) {
-      const double p1 = (rok && c1ok) ? panel[i + ld * (16 + lcol)] : 0.0;
+      const double p1 = (rok && c1ok) ? (double)panel[i + ld * (16 + lcol)] : 0.0;
       a01 = __builtin_amdgcn_mfma_f64_16x16x4f64(p0, p1, a01, 0, 0, 0);
       a11 = __builtin_amdgcn_mfma_f64_16x16x4f64(p1, p1, a11, 0, 0, 0);
     }
@@ -66,7 +68,8 @@ __device__ __forceinline__ void gramian_wave(const double *panel, int rows, long
 }
 
 // Partial Gramian of rows [row0, row1) on the matrix cores (see gramian_wave); accumulators out.
-__device__ __forceinline__ void gramian_rows(const double *panel, int row0, int row1, int rows,
+template <typename T>
+__device__ __forceinline__ void gramian_rows(const T *panel, int row0, int row1, int rows,
                                              long long ld, int r, int lane, v4d &a00, v4d &a01,
                                              v4d &a11) {
   const int krow = lane >> 4, lcol = lane & 15;
@@ -75,12 +78,12 @@ __device__ __forceinline__ void gramian_rows(const double *panel, int row0, int 
   for (int i0 = row0; i0 < row1; i0 += 8) {
     const int ia = i0 + krow, ib = i0 + 4 + krow;
     const bool ra = ia < row1 && ia < rows, rb = ib < row1 && ib < rows;
-    const double p0a = (ra && c0ok) ? panel[ia + ld * lcol] : 0.0;
-    const double p0b = (rb && c0ok) ? panel[ib + ld * lcol] : 0.0;
+    const double p0a = (ra && c0ok) ? (double)panel[ia + ld * lcol] : 0.0;
+    const double p0b = (rb && c0ok) ? (double)panel[ib + ld * lcol] : 0.0;
     double p1a = 0.0, p1b = 0.0;
     if (two) {
-      p1a = (ra && c1ok) ? panel[ia + ld * (16 + lcol)] : 0.0;
-      p1b = (rb && c1ok) ? panel[ib + ld * (16 + lcol)] : 0.0;
+      p1a = (ra && c1ok) ? (double)panel[ia + ld * (16 + lcol)] : 0.0;
+      p1b = (rb && c1ok) ? (double)panel[ib + ld * (16 + lcol)] : 0.0;
     }
     a00 = __builtin_amdgcn_mfma_f64_16x16x4f64(p0a, p0a, a00, 0, 0, 0);
     if (two) {
@@ -113,7 +116,7 @@ struct UpdShared {
 
 // noinline: inlining all rank classes into one kernel made the register allocator spill heavily
 // (each body alone fits); as separate functions each gets its own allocation.
-template <int RMAX>
+template <int RMAX, typename T>
 __device__ __attribute__((noinline)) void update_body(const UpdateArgs &a, int slot, int r,
                                                       UpdShared &sh) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -168,7 +171,8 @@ __device__ __attribute__((noinline)) void update_body(const UpdateArgs &a, int s
   __syncthreads();
   const double *dinv = sh.dinv;
 
-  double *fac = a.factor + (long long)I * col;
+  // storage type T (double | float); all arithmetic below is fp64
+  T *fac = static_cast<T *>(a.factor) + (long long)I * col;
   const bool first = (iters == 1);
 
   // per-column statistics of this thread's rows: first sweep: st1 = sum of squares; later:
@@ -193,7 +197,7 @@ __device__ __attribute__((noinline)) void update_body(const UpdateArgs &a, int s
     // (the reference's MTTKRP overwrites factor n too, src/utils/mttkrp.cpp:311)
 #pragma unroll
     for (int c = 0; c < RMAX; ++c) {
-      x[c] = (c < r) ? fac[i + (long long)I * c] : 0.0;
+      x[c] = (c < r) ? (double)fac[i + (long long)I * c] : 0.0;
       g[c] = x[c];
     }
     // B := B * inv(L^T)   (dtrsm Right, Lower, Trans)
@@ -223,7 +227,7 @@ __device__ __attribute__((noinline)) void update_body(const UpdateArgs &a, int s
 #pragma unroll
     for (int c = 0; c < RMAX; ++c) {
       if (c < r) {
-        fac[i + (long long)I * c] = x[c];
+        fac[i + (long long)I * c] = (T)x[c];
         t3 += x[c] * g[c];  // = lambda_c * A[i,c] * G[i,c] of compute_fast_error's term3
         if (first) {
           st1[c] += x[c] * x[c];
@@ -304,7 +308,7 @@ __device__ __attribute__((noinline)) void update_body(const UpdateArgs &a, int s
     for (int c = 0; c < RMAX; ++c) {
       if (c < r) {
         const double lam = lams[c];
-        if (lam != 0.0) fac[i + (long long)I * c] = (1.0 / lam) * fac[i + (long long)I * c];
+        if (lam != 0.0) fac[i + (long long)I * c] = (T)((1.0 / lam) * (double)fac[i + (long long)I * c]);
       }
     }
   }
@@ -375,35 +379,38 @@ __device__ __attribute__((noinline)) void update_body(const UpdateArgs &a, int s
   }
 }
 
+template <typename T>
 __global__ void __launch_bounds__(UPD_THREADS, 1) update_kernel(const UpdateArgs a) {
   __shared__ UpdShared sh;
   const int slot = a.slots[blockIdx.x];
   const int r = a.mt.rank[slot];
   if (r <= 4)
-    update_body<4>(a, slot, r, sh);
+    update_body<4, T>(a, slot, r, sh);
   else if (r <= 8)
-    update_body<8>(a, slot, r, sh);
+    update_body<8, T>(a, slot, r, sh);
   else if (r <= 12)
-    update_body<12>(a, slot, r, sh);
+    update_body<12, T>(a, slot, r, sh);
   else if (r <= 16)
-    update_body<16>(a, slot, r, sh);
+    update_body<16, T>(a, slot, r, sh);
   else if (r <= 20)
-    update_body<20>(a, slot, r, sh);
+    update_body<20, T>(a, slot, r, sh);
   else if (r <= 24)
-    update_body<24>(a, slot, r, sh);
+    update_body<24, T>(a, slot, r, sh);
   else
-    update_body<32>(a, slot, r, sh);
+    update_body<32, T>(a, slot, r, sh);
 }
 
 // G[i, c] = sum_t partial[(c / 128) * T + t][i, c % 128], t = 0..T-1 in this fixed order
-// (deterministic split-K reduction of the MTTKRP), written into the multi-factor of the mode.
-__global__ void __launch_bounds__(256) reduce_partials_kernel(const double *partial, int T,
-                                                              int ldPart, int I, double *factor) {
+// (deterministic split-K reduction of the MTTKRP, summed in fp64), written into the multi-factor
+// of the mode.
+template <typename E>
+__global__ void __launch_bounds__(256) reduce_partials_kernel(const E *partial, int T, int ldPart,
+                                                              int I, E *factor) {
   const int c = blockIdx.y;
   const long long tile = (long long)ldPart * CALS_BN;
-  const double *base = partial + (long long)(c >> 7) * T * tile + (long long)ldPart * (c & (CALS_BN - 1));
+  const E *base = partial + (long long)(c >> 7) * T * tile + (long long)ldPart * (c & (CALS_BN - 1));
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < I; i += gridDim.x * blockDim.x) {
-    const double *p = base + i;
+    const E *p = base + i;
     double s = 0.0;
     int t = 0;
     for (; t + 4 <= T; t += 4) {
@@ -414,16 +421,21 @@ __global__ void __launch_bounds__(256) reduce_partials_kernel(const double *part
       s += v2;
       s += v3;
     }
-    for (; t < T; ++t) s += p[t * tile];
-    factor[i + (long long)I * c] = s;
+    for (; t < T; ++t) s += (double)p[t * tile];
+    factor[i + (long long)I * c] = (E)s;
   }
 }
 
-hipError_t reduce_partials_launch(const double *partial, int T, int ldPart, int I, int R,
-                                  double *factor, hipStream_t st) {
+hipError_t reduce_partials_launch(const void *partial, int T, int ldPart, int I, int R,
+                                  void *factor, int dtype, hipStream_t st) {
   if (R <= 0) return hipSuccess;
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((I + 255) / 256, R), dim3(256), 0, st, partial, T,
-                     ldPart, I, factor);
+  const dim3 grid((I + 255) / 256, R), block(256);
+  if (dtype == CALS_F32)
+    hipLaunchKernelGGL(reduce_partials_kernel<float>, grid, block, 0, st, (const float *)partial, T,
+                       ldPart, I, (float *)factor);
+  else
+    hipLaunchKernelGGL(reduce_partials_kernel<double>, grid, block, 0, st, (const double *)partial,
+                       T, ldPart, I, (double *)factor);
   return hipGetLastError();
 }
 
@@ -454,25 +466,32 @@ hipError_t init_slots_launch(const int *desc, int n, const ModelTable &mt, hipSt
 
 hipError_t update_launch(const UpdateArgs &a, int, hipStream_t st) {
   if (a.n_slots <= 0) return hipSuccess;
-  hipLaunchKernelGGL(update_kernel, dim3(a.n_slots), dim3(UPD_THREADS), 0, st, a);
+  if (a.dtype == CALS_F32)
+    hipLaunchKernelGGL(update_kernel<float>, dim3(a.n_slots), dim3(UPD_THREADS), 0, st, a);
+  else
+    hipLaunchKernelGGL(update_kernel<double>, dim3(a.n_slots), dim3(UPD_THREADS), 0, st, a);
   return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------------
 // Gramians at admission (MultiKtensor::add, src/multi_ktensor.cpp:88-94)
 // ---------------------------------------------------------------------------------------------
+template <typename T>
 __global__ void __launch_bounds__(64) gram_init_kernel(const GramInitArgs a) {
   const int slot = a.slots[blockIdx.x];
   const int m = blockIdx.y;
   const int col = a.mt.col[slot];
   const int r = a.mt.rank[slot];
-  gramian_wave(a.factor[m] + (long long)a.I[m] * col, a.I[m], a.I[m], r,
-               a.gram[m] + CALS_RMAX * (long long)col, threadIdx.x);
+  gramian_wave<T>(static_cast<const T *>(a.factor[m]) + (long long)a.I[m] * col, a.I[m], a.I[m], r,
+                  a.gram[m] + CALS_RMAX * (long long)col, threadIdx.x);
 }
 
 hipError_t gram_init_launch(const GramInitArgs &a, hipStream_t st) {
   if (a.n_slots <= 0) return hipSuccess;
-  hipLaunchKernelGGL(gram_init_kernel, dim3(a.n_slots, a.n_modes), dim3(64), 0, st, a);
+  if (a.dtype == CALS_F32)
+    hipLaunchKernelGGL(gram_init_kernel<float>, dim3(a.n_slots, a.n_modes), dim3(64), 0, st, a);
+  else
+    hipLaunchKernelGGL(gram_init_kernel<double>, dim3(a.n_slots, a.n_modes), dim3(64), 0, st, a);
   return hipGetLastError();
 }
 
@@ -480,18 +499,22 @@ hipError_t gram_init_launch(const GramInitArgs &a, hipStream_t st) {
 // line search (NO_ERROR_CHECKING)
 // ---------------------------------------------------------------------------------------------
 // prev_ktensor.copy(ktensor) when ls.iter == interval-1 (src/cals.cpp:203-211)
+template <typename T>
 __global__ void __launch_bounds__(256) ls_snapshot_kernel(const LsArgs a) {
   const int slot = a.slots[blockIdx.x];
   if (a.mt.ls_iter[slot] != a.interval - 1) return;
   const int col = a.mt.col[slot], r = a.mt.rank[slot];
   for (int m = 0; m < a.n_modes; ++m) {
     const long long n = (long long)a.I[m] * r, off = (long long)a.I[m] * col;
-    for (long long e = threadIdx.x; e < n; e += 256) a.prev[m][off + e] = a.factor[m][off + e];
+    const T *src = static_cast<const T *>(a.factor[m]);
+    T *dst = static_cast<T *>(a.prev[m]);
+    for (long long e = threadIdx.x; e < n; e += 256) dst[off + e] = src[off + e];
   }
   if (threadIdx.x < r) a.prev_lambda[col + threadIdx.x] = a.lambda[col + threadIdx.x];
 }
 
 // ls::line_search (src/utils/line_search.cpp:228-271) for every model, after the error update.
+template <typename T>
 __global__ void __launch_bounds__(256) ls_kernel(const LsArgs a) {
   const int slot = a.slots[blockIdx.x];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -512,7 +535,9 @@ __global__ void __launch_bounds__(256) ls_kernel(const LsArgs a) {
       ls_iter = 0;
       for (int m = 0; m < a.n_modes; ++m) {
         const long long n = (long long)a.I[m] * r, off = (long long)a.I[m] * col;
-        for (long long e = tid; e < n; e += 256) a.factor[m][off + e] = a.backup[m][off + e];
+        T *dst = static_cast<T *>(a.factor[m]);
+        const T *src = static_cast<const T *>(a.backup[m]);
+        for (long long e = tid; e < n; e += 256) dst[off + e] = src[off + e];
       }
       if (tid < r) a.lambda[col + tid] = a.backup_lambda[col + tid];
       regram = true;
@@ -537,7 +562,9 @@ __global__ void __launch_bounds__(256) ls_kernel(const LsArgs a) {
     // backup_ktensor.copy(ktensor)
     for (int m = 0; m < a.n_modes; ++m) {
       const long long n = (long long)a.I[m] * r, off = (long long)a.I[m] * col;
-      for (long long e = tid; e < n; e += 256) a.backup[m][off + e] = a.factor[m][off + e];
+      T *dst = static_cast<T *>(a.backup[m]);
+      const T *src = static_cast<const T *>(a.factor[m]);
+      for (long long e = tid; e < n; e += 256) dst[off + e] = src[off + e];
     }
     if (tid < r) a.backup_lambda[col + tid] = a.lambda[col + tid];
     if (tid == 0) {
@@ -554,8 +581,8 @@ __global__ void __launch_bounds__(256) ls_kernel(const LsArgs a) {
       const double lc = a.lambda[col + c], lp = a.prev_lambda[col + c];
       double lam = 1.0;
       for (int m = 0; m < a.n_modes; ++m) {
-        double *f = a.factor[m] + (long long)a.I[m] * (col + c);
-        const double *pf = a.prev[m] + (long long)a.I[m] * (col + c);
+        T *f = static_cast<T *>(a.factor[m]) + (long long)a.I[m] * (col + c);
+        const T *pf = static_cast<const T *>(a.prev[m]) + (long long)a.I[m] * (col + c);
         double ss = 0.0;
         for (int i = lane; i < a.I[m]; i += 64) {
           double x = f[i], p = pf[i];
@@ -564,12 +591,12 @@ __global__ void __launch_bounds__(256) ls_kernel(const LsArgs a) {
             p *= lp;
           }
           x += step * (x - p);
-          f[i] = x;
+          f[i] = (T)x;
           ss += x * x;
         }
         const double coeff = sqrt(wave_sum(ss));
         const double s = 1.0 / coeff;
-        for (int i = lane; i < a.I[m]; i += 64) f[i] = s * f[i];
+        for (int i = lane; i < a.I[m]; i += 64) f[i] = (T)(s * (double)f[i]);
         lam *= coeff;
       }
       if (lane == 0) a.lambda[col + c] = lam;
@@ -585,8 +612,8 @@ __global__ void __launch_bounds__(256) ls_kernel(const LsArgs a) {
   __syncthreads();
   if (regram) {  // update_gramians
     for (int m = wave; m < a.n_modes; m += 4)
-      gramian_wave(a.factor[m] + (long long)a.I[m] * col, a.I[m], a.I[m], r,
-                   a.gram[m] + CALS_RMAX * (long long)col, lane);
+      gramian_wave<T>(static_cast<const T *>(a.factor[m]) + (long long)a.I[m] * col, a.I[m], a.I[m], r,
+                      a.gram[m] + CALS_RMAX * (long long)col, lane);
   }
   if (tid == 0) {
     a.mt.ls_iter[slot] = ls_iter;
@@ -597,13 +624,19 @@ __global__ void __launch_bounds__(256) ls_kernel(const LsArgs a) {
 
 hipError_t ls_snapshot_launch(const LsArgs &a, hipStream_t st) {
   if (a.n_slots <= 0) return hipSuccess;
-  hipLaunchKernelGGL(ls_snapshot_kernel, dim3(a.n_slots), dim3(256), 0, st, a);
+  if (a.dtype == CALS_F32)
+    hipLaunchKernelGGL(ls_snapshot_kernel<float>, dim3(a.n_slots), dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL(ls_snapshot_kernel<double>, dim3(a.n_slots), dim3(256), 0, st, a);
   return hipGetLastError();
 }
 
 hipError_t ls_launch(const LsArgs &a, hipStream_t st) {
   if (a.n_slots <= 0) return hipSuccess;
-  hipLaunchKernelGGL(ls_kernel, dim3(a.n_slots), dim3(256), 0, st, a);
+  if (a.dtype == CALS_F32)
+    hipLaunchKernelGGL(ls_kernel<float>, dim3(a.n_slots), dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL(ls_kernel<double>, dim3(a.n_slots), dim3(256), 0, st, a);
   return hipGetLastError();
 }
 
@@ -640,8 +673,8 @@ hipError_t finish_launch(const FinishArgs &a, hipStream_t st) {
 // Xp[m + Mp*(a + Ap*s)] = X[...] with the output mode `m_mode` fastest, then the inner mode
 // `a_mode`, then the remaining modes in increasing order (first fastest); pads are zero.
 struct PermArgs {
-  const double *X;
-  double *Xp;
+  const void *X;
+  void *Xp;
   int n_modes;
   int dims[CALS_MAX_MODES];
   long long stride[CALS_MAX_MODES];  // element stride of every mode in X
@@ -650,6 +683,7 @@ struct PermArgs {
   long long S;
 };
 
+template <typename S, typename T>
 __global__ void permute_pad_kernel(const PermArgs a) {
   const long long total = (long long)a.Mp * a.Ap * a.S;
   const int M = a.dims[a.m_mode], A = a.dims[a.a_mode];
@@ -667,14 +701,14 @@ __global__ void permute_pad_kernel(const PermArgs a) {
         off += (s % a.dims[k]) * a.stride[k];
         s /= a.dims[k];
       }
-      v = a.X[off];
+      v = (double)static_cast<const S *>(a.X)[off];
     }
-    a.Xp[e] = v;
+    static_cast<T *>(a.Xp)[e] = (T)v;
   }
 }
 
-hipError_t permute_pad_launch(const double *X, int n_modes, const int *dims, int m_mode,
-                              int a_mode, int Mp, int Ap, double *Xp, long long S,
+hipError_t permute_pad_launch(const void *X, int src_dtype, int n_modes, const int *dims, int m_mode,
+                              int a_mode, int Mp, int Ap, void *Xp, int dst_dtype, long long S,
                               hipStream_t st) {
   PermArgs a;
   a.X = X;
@@ -691,21 +725,29 @@ hipError_t permute_pad_launch(const double *X, int n_modes, const int *dims, int
   a.Mp = Mp;
   a.Ap = Ap;
   a.S = S;
-  hipLaunchKernelGGL(permute_pad_kernel, dim3(4096), dim3(256), 0, st, a);
+  if (src_dtype == CALS_F32 && dst_dtype == CALS_F32)
+    hipLaunchKernelGGL((permute_pad_kernel<float, float>), dim3(4096), dim3(256), 0, st, a);
+  else if (src_dtype == CALS_F32)
+    hipLaunchKernelGGL((permute_pad_kernel<float, double>), dim3(4096), dim3(256), 0, st, a);
+  else if (dst_dtype == CALS_F32)
+    hipLaunchKernelGGL((permute_pad_kernel<double, float>), dim3(4096), dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL((permute_pad_kernel<double, double>), dim3(4096), dim3(256), 0, st, a);
   return hipGetLastError();
 }
 
 // Sum of squares of every mode-0 slice (utils::calculate_jackknifing_norms, utils.cpp:103-152),
 // deterministic: stage 1 = n_part blocks each reduce a contiguous range of columns into
 // partial[b][i]; stage 2 = ordered sum over b.
-__global__ void slice_sumsq_stage1(const double *X, long long I, long long cols, double *partial,
+template <typename S>
+__global__ void slice_sumsq_stage1(const S *X, long long I, long long cols, double *partial,
                                    int n_part) {
   const int b = blockIdx.x;
   const long long c0 = cols * b / n_part, c1 = cols * (b + 1) / n_part;
   for (long long i = threadIdx.x; i < I; i += blockDim.x) {
     double s = 0.0;
     for (long long c = c0; c < c1; ++c) {
-      const double v = X[i + I * c];
+      const double v = (double)X[i + I * c];
       s += v * v;
     }
     partial[(long long)b * I + i] = s;
@@ -720,10 +762,14 @@ __global__ void slice_sumsq_stage2(const double *partial, long long I, int n_par
   ss[i] = s;
 }
 
-hipError_t slice_sumsq_launch(const double *X, long long I, long long cols, double *partial,
-                              int n_part, double *ss_out, hipStream_t st) {
-  hipLaunchKernelGGL(slice_sumsq_stage1, dim3(n_part), dim3(256), 0, st, X, I, cols, partial,
-                     n_part);
+hipError_t slice_sumsq_launch(const void *X, int src_dtype, long long I, long long cols,
+                              double *partial, int n_part, double *ss_out, hipStream_t st) {
+  if (src_dtype == CALS_F32)
+    hipLaunchKernelGGL(slice_sumsq_stage1<float>, dim3(n_part), dim3(256), 0, st, (const float *)X, I,
+                       cols, partial, n_part);
+  else
+    hipLaunchKernelGGL(slice_sumsq_stage1<double>, dim3(n_part), dim3(256), 0, st, (const double *)X,
+                       I, cols, partial, n_part);
   hipLaunchKernelGGL(slice_sumsq_stage2, dim3((unsigned)((I + 255) / 256)), dim3(256), 0, st,
                      partial, I, n_part, ss_out);
   return hipGetLastError();
@@ -731,21 +777,26 @@ hipError_t slice_sumsq_launch(const double *X, long long I, long long cols, doub
 
 // compress: move ncols columns starting at src_col left by off columns; one block walks the
 // columns in ascending order (destination < source, so this is overlap-safe).
-__global__ void move_columns_kernel(double *buf, long long rows, long long src_col,
-                                    long long ncols, long long off) {
+template <typename E>
+__global__ void move_columns_kernel(E *buf, long long rows, long long src_col, long long ncols,
+                                    long long off) {
   for (long long c = 0; c < ncols; ++c) {
-    const double *s = buf + rows * (src_col + c);
-    double *d = buf + rows * (src_col + c - off);
+    const E *s = buf + rows * (src_col + c);
+    E *d = buf + rows * (src_col + c - off);
     for (long long i = threadIdx.x; i < rows; i += blockDim.x) d[i] = s[i];
     __syncthreads();
   }
 }
 
-hipError_t move_columns_launch(double *buf, long long rows, long long src_col, long long ncols,
-                               long long off, hipStream_t st) {
+hipError_t move_columns_launch(void *buf, int dtype, long long rows, long long src_col,
+                               long long ncols, long long off, hipStream_t st) {
   if (ncols <= 0 || off <= 0) return hipSuccess;
-  hipLaunchKernelGGL(move_columns_kernel, dim3(1), dim3(256), 0, st, buf, rows, src_col, ncols,
-                     off);
+  if (dtype == CALS_F32)
+    hipLaunchKernelGGL(move_columns_kernel<float>, dim3(1), dim3(256), 0, st, (float *)buf, rows,
+                       src_col, ncols, off);
+  else
+    hipLaunchKernelGGL(move_columns_kernel<double>, dim3(1), dim3(256), 0, st, (double *)buf, rows,
+                       src_col, ncols, off);
   return hipGetLastError();
 }
 

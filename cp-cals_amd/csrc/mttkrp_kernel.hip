@@ -131,7 +131,7 @@ __global__ void __launch_bounds__(512, 2) mttkrp_kernel(const MttkrpArgs a) {
 #pragma unroll
     for (int j = 0; j < C::SB; ++j) {
       if (j < n) {
-        const double *src_slab = a.Xp + (long long)a.Mp * (16 * ab) + slab_stride_s * (s0 + j);
+        const double *src_slab = static_cast<const double *>(a.Xp) + (long long)a.Mp * (16 * ab) + slab_stride_s * (s0 + j);
         double *dst_slab = lds + buf * C::STAGE + j * C::SLAB;
 #pragma unroll
         for (int pc = 0; pc < (C::PIECES + 7) / 8; ++pc) {
@@ -164,7 +164,7 @@ __global__ void __launch_bounds__(512, 2) mttkrp_kernel(const MttkrpArgs a) {
         const int d = (piece & 3) * 32 + (lane >> 1);
         int c = nb * CALS_BN + d;
         c = c < a.R ? c : 0;  // columns past R: any valid address, result never read
-        const char *src = (const char *)(a.Q + (s0 + j) + a.ldQ * c) + 4 * (lane & 1);
+        const char *src = (const char *)(static_cast<const double *>(a.Q) + (s0 + j) + a.ldQ * c) + 4 * (lane & 1);
         __builtin_amdgcn_global_load_lds((const GLOBAL_AS void *)src,
                                          (LDS_AS void *)(qlds + buf * C::QSTAGE + piece * 32), 4, 0,
                                          0);
@@ -208,7 +208,7 @@ __global__ void __launch_bounds__(512, 2) mttkrp_kernel(const MttkrpArgs a) {
       for (int q = 0; q < 4; ++q) {
         const int arow = (int)(16 * ab_c) + 4 * q + krow;
         const bool ok = (arow < a.A) && cvalid;
-        const double *ptr = a.P + (ok ? arow + a.ldP * col : 0);
+        const double *ptr = static_cast<const double *>(a.P) + (ok ? arow + a.ldP * col : 0);
         double v;
         asm volatile("global_load_dwordx2 %0, %1, off\n\ts_waitcnt vmcnt(0)"
                      : "=&v"(v)
@@ -324,7 +324,7 @@ __global__ void __launch_bounds__(512, 2) mttkrp_kernel(const MttkrpArgs a) {
   }
   // ---- epilogue: partial tile [ldPart x 128] of (nb, tm); f64 MFMA C/D layout:
   // lane holds D[row = (lane>>4) + 4*reg][col = lane&15]
-  double *pt = a.partial + ((long long)(nb * a.T + tm)) * ((long long)a.ldPart * CALS_BN);
+  double *pt = static_cast<double *>(a.partial) + ((long long)(nb * a.T + tm)) * ((long long)a.ldPart * CALS_BN);
   const int cl = wave * 16 + lcol;
 #pragma unroll
   for (int t = 0; t < MT; ++t) {
@@ -400,6 +400,7 @@ hipError_t mttkrp_launch(int MT, int m_blocks, const MttkrpArgs &a, hipStream_t 
 
 // Khatri-Rao of the streamed modes (N > 3): Q[s, c] = prod_k F_k[i_k(s), c], first mode fastest.
 // Restates khatri_rao_rec's ordering (src/utils/mttkrp.cpp:147-176).  Small next to the MTTKRP.
+template <typename E>
 __global__ void krp_kernel(const KrpArgs a) {
   const long long total = a.S * a.R;
   for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total;
@@ -410,9 +411,9 @@ __global__ void krp_kernel(const KrpArgs a) {
     for (int k = 0; k < a.n; ++k) {
       const long long i = s % a.dims[k];
       s /= a.dims[k];
-      v *= a.F[k][i + a.ld[k] * c];
+      v *= (double)static_cast<const E *>(a.F[k])[i + a.ld[k] * c];
     }
-    a.Q[e] = v;
+    static_cast<E *>(a.Q)[e] = (E)v;
   }
 }
 
@@ -421,7 +422,10 @@ hipError_t krp_launch(const KrpArgs &a, hipStream_t st) {
   if (total <= 0) return hipSuccess;
   long long blocks = (total + 255) / 256;
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(krp_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a);
+  if (a.dtype == CALS_F32)
+    hipLaunchKernelGGL(krp_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL(krp_kernel<double>, dim3((unsigned)blocks), dim3(256), 0, st, a);
   return hipGetLastError();
 }
 

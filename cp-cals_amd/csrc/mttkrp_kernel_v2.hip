@@ -68,7 +68,7 @@ __device__ __forceinline__ void mttkrp2_body(const MttkrpArgs &a, double *lds, i
 #pragma unroll
     for (int j = 0; j < C::SB; ++j) {
       if (j < n) {
-        const double *src_slab = a.Xp + (long long)a.Mp * (16 * ab) + slab_stride_s * (s0 + j);
+        const double *src_slab = static_cast<const double *>(a.Xp) + (long long)a.Mp * (16 * ab) + slab_stride_s * (s0 + j);
         double *dst_slab = lds + buf * C::STAGE + j * C::SLAB;
 #pragma unroll
         for (int pc = 0; pc < (C::PIECES + 3) / 4; ++pc) {
@@ -94,7 +94,7 @@ __device__ __forceinline__ void mttkrp2_body(const MttkrpArgs &a, double *lds, i
         const int d = (piece & 3) * 32 + (lane >> 1);
         int c = nb * CALS_BN + d;
         c = c < a.R ? c : 0;  // columns past R: any valid address, result never read
-        const char *src = (const char *)(a.Q + (s0 + j) + a.ldQ * c) + 4 * (lane & 1);
+        const char *src = (const char *)(static_cast<const double *>(a.Q) + (s0 + j) + a.ldQ * c) + 4 * (lane & 1);
         __builtin_amdgcn_global_load_lds((const GLOBAL_AS void *)src,
                                          (LDS_AS void *)(qlds + buf * C::QSTAGE + piece * 32), 4, 0,
                                          0);
@@ -145,7 +145,7 @@ __device__ __forceinline__ void mttkrp2_body(const MttkrpArgs &a, double *lds, i
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
           const bool ok = (arow < a.A) && cvalid[nt];
-          const double *ptr = a.P + (ok ? arow + a.ldP * col[nt] : 0);
+          const double *ptr = static_cast<const double *>(a.P) + (ok ? arow + a.ldP * col[nt] : 0);
           double v;
           asm volatile("global_load_dwordx2 %0, %1, off\n\ts_waitcnt vmcnt(0)"
                        : "=&v"(v)
@@ -198,7 +198,7 @@ __device__ __forceinline__ void mttkrp2_body(const MttkrpArgs &a, double *lds, i
     buf ^= 1;
   }
 
-  double *pt = a.partial + ((long long)(nb * a.T + tm)) * ((long long)a.ldPart * CALS_BN);
+  double *pt = static_cast<double *>(a.partial) + ((long long)(nb * a.T + tm)) * ((long long)a.ldPart * CALS_BN);
 #pragma unroll
   for (int t = 0; t < MT; ++t) {
 #pragma unroll

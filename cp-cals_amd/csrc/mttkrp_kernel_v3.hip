@@ -1,24 +1,38 @@
-// Fused MTTKRP, third schedule ("v3"): same mathematics, layout and wave tile as mttkrp_kernel.hip
-//   G[m, c] = sum_{a, s} Xp[m, a, s] * P[a, c] * Q[s, c],   8 waves x (MT m-tiles x 16 columns),
-// but the stage boundary bubble is removed.  Measured on v1 (tools/clock_probe.py): the pipe
-// idles ~1800 of every 21 300 cycles because all 8 waves leave the end-of-stage barrier together and
-// refill their operand pipelines (LDS latency, address set-up) at the same time.  Here:
+// Fused MTTKRP of the multi-factor block on gfx950, default schedule ("v3"), fp64 and fp32 storage:
+//
+//   G[m, c] = sum_{a, s} Xp[m, a, s] * P[a, c] * Q[s, c]          c < R (all in-flight models)
+//
+// = mttkrp::mttkrp of the reference (src/utils/mttkrp.cpp:562-614) with the Khatri-Rao product
+// (:78-216) never materialised: the B operand of every v_mfma_{f64,f32}_16x16x4 is formed in
+// registers as P[a,c]*Q[s,c].  Data layout and work decomposition: DESIGN.md section 2/3.1 and the
+// header of mttkrp_kernel.hip (v1).  Same wave tile as v1 (8 waves x (MT m-tiles x 16 columns)),
+// but the stage-boundary bubble measured on v1 (tools/clock_probe.py: the pipe idled ~1800 of every
+// 21 300 cycles because all 8 waves left the end-of-stage barrier together and refilled their
+// operand pipelines at the same time) is removed:
 //   * one slab per stage, a ring of THREE LDS buffers;
-//   * the only barrier of a stage sits in the MIDDLE of its MFMA stream, where every wave's
-//     operand ring is full: "DMA(i+1) has landed for everybody" and "everybody has left stage i-1,
-//     so its buffer may be overwritten" are both true there; DMA(i+2) is issued right behind it,
-//     one 1-KiB piece per MFMA step, in the shadow of the 64-cycle MFMAs;
+//   * the only barrier of a stage sits in the MIDDLE of its MFMA stream (waves 0-3) or at its
+//     start (waves 4-7: stagger, MI355X_MICROARCH "two waves per SIMD" item 9): there "slab i+1 has
+//     landed for everybody" and "everybody has left slab i-1, so its buffer may be overwritten" are
+//     both true; DMA(i+2) is issued right behind it, one 1-KiB piece per MFMA step, in the shadow
+//     of the MFMAs;
 //   * no barrier at the stage boundary: each wave refills its operand ring for the next slab on its
-//     own schedule, so the two waves of a SIMD do it at different times and cover each other.
-// A operands and Q are read by inline-asm ds_read_b64 with counted s_waitcnt lgkmcnt (see SlabPipe
-// in mttkrp_kernel.hip for why); nothing else in the loop touches the LGKM counter.
+//     own schedule.
+// A operands and Q are read by inline-asm ds_read with COUNTED s_waitcnt lgkmcnt(n) (LDS returns in
+// order, so "all but the n youngest reads" is exactly "operand I has landed"; hipcc's own waits for
+// this pattern are lgkmcnt(0)).  The reads are invisible to hipcc's counters, so every wait is placed
+// here; sched_barrier(0) keeps the MFMA below its wait (guide rule 18); no in-flight inline-asm load
+// is live across the loop back-edge (hipcc copies registers there -- found as a real bug).
+// Nothing the loop consumes comes from an ordinary global load (hipcc would drain vmcnt(0) inside
+// the MFMA loop): P is loaded by an inline-asm load with its own wait once per a-block.
 #include "cals_hip_internal.h"
 
+#include <type_traits>
 #include <utility>
 
 namespace calship {
 
 typedef double v4d __attribute__((ext_vector_type(4)));
+typedef float v4f __attribute__((ext_vector_type(4)));
 
 #define GLOBAL_AS __attribute__((address_space(1)))
 #define LDS_AS __attribute__((address_space(3)))
@@ -35,69 +49,100 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 #define CALS_V3_RING 6
 #endif
 
-template <int MT>
+template <int MT, typename T>
 struct Mt3Cfg {
-  static constexpr int RING = CALS_V3_RING;
-  static constexpr int LDL = (MT % 2 == 1) ? 16 * MT : 16 * MT + 16;
-  static constexpr int SLAB = 16 * LDL;        // doubles per slab
-  static constexpr int BUF = SLAB + CALS_BN;   // + the slab's 128 Q values
-  static constexpr int PIECES = LDL / 8;       // 1 KiB DMA pieces per slab
-  static constexpr int NP = (PIECES + 7) / 8;  // pieces per wave (upper bound)
-  static constexpr int LDS_BYTES = 3 * BUF * 8;
-  static constexpr int N = 4 * MT;             // MFMAs (= A operands) per slab per wave
-  static constexpr int D = N < RING ? N : RING;  // operand ring depth
-  static constexpr int H = N / 2;              // barrier position
+  static constexpr int ES = (int)sizeof(T);
+  static constexpr int LDL = (MT % 2 == 1) ? 16 * MT : 16 * MT + 16;  // elements; = 16 mod 32
+  static constexpr int SLAB = 16 * LDL;              // elements per slab
+  static constexpr int BUF = SLAB + CALS_BN;         // + the slab's 128 Q values
+  static constexpr int PE = 1024 / ES;               // elements per 1-KiB DMA piece
+  static constexpr int PIECES = SLAB / PE;           // LDL/8 (f64) or LDL/16 (f32): exact
+  static constexpr int NP = (PIECES + 7) / 8;        // slab pieces per wave (upper bound)
+  static constexpr int QPE = 256 / ES;               // Q elements per 4-byte-per-lane DMA piece
+  static constexpr int QPIECES = CALS_BN / QPE;      // 4 (f64) or 2 (f32)
+  static constexpr int LDS_BYTES = 3 * BUF * ES;
+  static constexpr int N = 4 * MT;                   // MFMAs (= A operands) per slab per wave
+  static constexpr int RING = std::is_same<T, float>::value ? CALS_V3_RING + 2 : CALS_V3_RING;
+  static constexpr int D = N < RING ? N : RING;      // operand ring depth
+  static constexpr int H = N / 2;                    // barrier position
 };
 
-// per-wave DMA state: everything issue_piece needs, precomputed per stage
-struct DmaCtx {
-  const double *src_slab;  // Xp slab base for the stage being fetched
-  const double *q_src;     // &Q[s, 0] for that stage
-  double *dst;             // LDS buffer base (slab then Q)
+template <typename T> struct Acc;
+template <> struct Acc<double> {
+  typedef v4d type;
+  static __device__ __forceinline__ v4d mfma(double a, double b, v4d c) {
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+  }
+  // f64 C/D layout: lane holds D[row = (lane>>4) + 4*reg][col = lane&15]
+  static __device__ __forceinline__ int row(int krow, int reg) { return krow + 4 * reg; }
+};
+template <> struct Acc<float> {
+  typedef v4f type;
+  static __device__ __forceinline__ v4f mfma(float a, float b, v4f c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+  }
+  // f32 C/D layout: lane holds D[row = 4*(lane>>4) + reg][col = lane&15]
+  static __device__ __forceinline__ int row(int krow, int reg) { return 4 * krow + reg; }
 };
 
-template <int MT>
+template <typename T>
+static __device__ __forceinline__ void lds_read(T &dst, unsigned addr);
+template <>
+__device__ __forceinline__ void lds_read<double>(double &dst, unsigned addr) {
+  asm volatile("ds_read_b64 %0, %1" : "=v"(dst) : "v"(addr));
+}
+template <>
+__device__ __forceinline__ void lds_read<float>(float &dst, unsigned addr) {
+  asm volatile("ds_read_b32 %0, %1" : "=v"(dst) : "v"(addr));
+}
+template <typename T, int OFF>
+static __device__ __forceinline__ void lds_read_off(T &dst, unsigned addr) {
+  if constexpr (std::is_same<T, double>::value)
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF));
+  else
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF));
+}
+
+template <int MT, typename T>
 struct Pipe3 {
-  typedef Mt3Cfg<MT> C;
+  typedef Mt3Cfg<MT, T> C;
+  typedef typename Acc<T>::type acc_t;
 
-  // one step: wait for operand I, MFMA, refill the ring slot (from this slab, or - near the end -
-  // from the next one), and on the steps behind the barrier issue one DMA piece
   // one MFMA step on slab operand I: counted wait, MFMA, refill of the ring slot with operand I+D
   template <int I>
-  static __device__ __forceinline__ void step(v4d (&acc)[MT], double (&ring)[C::D],
-                                              const double (&bq)[4], unsigned base) {
+  static __device__ __forceinline__ void step(acc_t (&acc)[MT], T (&ring)[C::D], const T (&bq)[4],
+                                              unsigned base) {
     // reads in flight behind operand I: the younger operands of this slab
     constexpr int outstanding = (C::D - 1 < C::N - 1 - I) ? C::D - 1 : C::N - 1 - I;
     asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(outstanding));
     __builtin_amdgcn_sched_barrier(0);
     constexpr int q = I / MT, t = I % MT;
-    acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ring[I % C::D], bq[q], acc[t], 0, 0, 0);
+    acc[t] = Acc<T>::mfma(ring[I % C::D], bq[q], acc[t]);
     if constexpr (I + C::D < C::N) {
       constexpr int qn = (I + C::D) / MT, tn = (I + C::D) % MT;
-      asm volatile("ds_read_b64 %0, %1 offset:%2"
-                   : "=v"(ring[I % C::D])
-                   : "v"(base), "i"(((4 * qn) * C::LDL + 16 * tn) * 8));
+      lds_read_off<T, ((4 * qn) * C::LDL + 16 * tn) * C::ES>(ring[I % C::D], base);
     }
   }
-  // the ring is local to a stage: an in-flight inline-asm load must never be live across the loop
-  // back-edge, where hipcc may copy registers
   template <int I>
-  static __device__ __forceinline__ void preload(double (&ring)[C::D], unsigned base) {
+  static __device__ __forceinline__ void preload(T (&ring)[C::D], unsigned base) {
     if constexpr (I < C::D) {
       constexpr int qn = I / MT, tn = I % MT;
-      asm volatile("ds_read_b64 %0, %1 offset:%2"
-                   : "=v"(ring[I])
-                   : "v"(base), "i"(((4 * qn) * C::LDL + 16 * tn) * 8));
+      lds_read_off<T, ((4 * qn) * C::LDL + 16 * tn) * C::ES>(ring[I], base);
       preload<I + 1>(ring, base);
     }
   }
 };
 
-template <int MT>
+template <int MT, typename T>
 __global__ void __launch_bounds__(512, 2) mttkrp3_kernel(const MttkrpArgs a) {
-  typedef Mt3Cfg<MT> C;
-  typedef Pipe3<MT> P3;
-  extern __shared__ __attribute__((aligned(16))) double lds[];
+  typedef Mt3Cfg<MT, T> C;
+  typedef Pipe3<MT, T> P3;
+  typedef typename Acc<T>::type acc_t;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  T *const lds = reinterpret_cast<T *>(lds_raw);
+  const T *const Xp = static_cast<const T *>(a.Xp);
+  const T *const Pm = static_cast<const T *>(a.P);
+  const T *const Qm = static_cast<const T *>(a.Q);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -107,7 +152,9 @@ __global__ void __launch_bounds__(512, 2) mttkrp3_kernel(const MttkrpArgs a) {
   const unsigned long long dbg_t0 = DIAG(a.dbg_clock) ? __builtin_amdgcn_s_memtime() : 0ull;
   const unsigned long long dbg_r0 = DIAG(a.dbg_clock) ? __builtin_amdgcn_s_memrealtime() : 0ull;
 
-  // XCD-aware bijective remap (see mttkrp_kernel.hip)
+  // XCD-aware bijective remap: workgroups that share an XCD (same blockIdx % 8) get consecutive
+  // p, i.e. the same team member of neighbouring column blocks => they stream the same Xp slabs
+  // through one L2 (speed only; any placement is correct).
   const int G = a.grid;
   const int b = blockIdx.x;
   const int xcd = b & 7, q8 = G >> 3, r8 = G & 7;
@@ -124,50 +171,53 @@ __global__ void __launch_bounds__(512, 2) mttkrp3_kernel(const MttkrpArgs a) {
   const int col = nb * CALS_BN + wave * 16 + lcol;
   const bool cvalid = col < a.R;
 
-  v4d acc[MT];
+  acc_t acc[MT];
 #pragma unroll
-  for (int t = 0; t < MT; ++t) acc[t] = (v4d){0.0, 0.0, 0.0, 0.0};
+  for (int t = 0; t < MT; ++t) acc[t] = (acc_t){0, 0, 0, 0};
 
   // ---- per-lane DMA source offsets (stage independent) ----
-  // piece k of this wave is global piece k*8 + wave: LDS element e = piece*128 + lane*2
+  // piece k of this wave is global piece k*8 + wave: LDS element e = piece*PE + lane*(16/ES)
   long long src_off[C::NP];
 #pragma unroll
   for (int k = 0; k < C::NP; ++k) {
     const int piece = k * 8 + wave;
-    const int e = piece * 128 + lane * 2;
+    const int e = piece * C::PE + lane * (16 / C::ES);
     const int acol = e / C::LDL;
     const int m = e - acol * C::LDL;
     int gm = m0 + m;
     gm = gm < a.Mp ? gm : 0;  // rows past the padded tensor: any valid address, unused
     src_off[k] = gm + (long long)a.Mp * acol;
   }
-  // Q piece: waves 0..3 fetch 32 doubles each by 4-byte LDS-DMA (two lanes per double)
+  // Q piece (4-byte LDS-DMA per lane): f64 = two lanes per value, waves 0..3; f32 = one lane per
+  // value, waves 0..1
   long long q_off;
+  int q_byte;
   {
-    const int d = wave * 32 + (lane >> 1);
+    const int d = wave * C::QPE + (C::ES == 8 ? (lane >> 1) : lane);
     int c = nb * CALS_BN + d;
-    c = c < a.R ? c : 0;  // columns past R: any valid address, result never read
-    q_off = a.ldQ * c;    // in doubles; + 4*(lane&1) bytes added at issue
+    c = (c < a.R && d < CALS_BN) ? c : 0;  // columns past R: any valid address, result never read
+    q_off = a.ldQ * c;
+    q_byte = (C::ES == 8) ? 4 * (lane & 1) : 0;
   }
   const long long slab_stride_s = (long long)a.Mp * a.Ap;
 
-  auto issue_piece = [&]<int K>(const double *src_slab, const double *q_row, double *dst) {
-    // K < NP: slab piece; K == NP: the Q piece (waves 0..3)
+  auto issue_piece = [&]<int K>(const T *src_slab, const T *q_row, T *dst) {
+    // K < NP: slab piece; K == NP: the Q piece
     if constexpr (K < C::NP) {
       const int piece = K * 8 + wave;
       if (piece < C::PIECES)
         __builtin_amdgcn_global_load_lds((const GLOBAL_AS void *)(src_slab + src_off[K]),
-                                         (LDS_AS void *)(dst + piece * 128), 16, 0, 0);
-    } else if (wave < 4) {
-      const char *src = (const char *)(q_row + q_off) + 4 * (lane & 1);
+                                         (LDS_AS void *)(dst + piece * C::PE), 16, 0, 0);
+    } else if (wave < C::QPIECES) {
+      const char *src = (const char *)(q_row + q_off) + q_byte;
       __builtin_amdgcn_global_load_lds((const GLOBAL_AS void *)src,
-                                       (LDS_AS void *)(dst + C::SLAB + wave * 32), 4, 0, 0);
+                                       (LDS_AS void *)(dst + C::SLAB + wave * C::QPE), 4, 0, 0);
     }
   };
   auto issue_all = [&](long long ab, long long s, int bufi) {
-    const double *src_slab = a.Xp + (long long)a.Mp * (16 * ab) + slab_stride_s * s;
-    const double *q_row = a.Q + s;
-    double *dst = lds + bufi * C::BUF;
+    const T *src_slab = Xp + (long long)a.Mp * (16 * ab) + slab_stride_s * s;
+    const T *q_row = Qm + s;
+    T *dst = lds + bufi * C::BUF;
     [&]<int... Ks>(std::integer_sequence<int, Ks...>) {
       (issue_piece.template operator()<Ks>(src_slab, q_row, dst), ...);
     }(std::make_integer_sequence<int, C::NP + 1>{});
@@ -182,18 +232,18 @@ __global__ void __launch_bounds__(512, 2) mttkrp3_kernel(const MttkrpArgs a) {
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  // (ab, s) of unit u+1 and u+2, kept incrementally
+  // (ab, s) of unit u+1 and u+2, kept incrementally (no 64-bit division in the loop)
   long long ab_1 = ab_c, s_1 = s_c + 1;
   if (s_1 >= S) { s_1 = 0; ab_1++; }
-  if (n_units > 1) issue_all(ab_1, s_1, 1);  // (kept under dbg_no_dma: results are then garbage anyway)
+  if (n_units > 1) issue_all(ab_1, s_1, 1);
   long long ab_2 = ab_1, s_2 = s_1 + 1;
   if (s_2 >= S) { s_2 = 0; ab_2++; }
 
-  const unsigned lane_off = (unsigned)((krow * C::LDL + lcol) * 8);
-  const unsigned lds0 = (unsigned)(size_t)((LDS_AS const char *)lds);
-  const unsigned q_lane_off = (unsigned)((C::SLAB + wave * 16 + lcol) * 8);
+  const unsigned lane_off = (unsigned)((krow * C::LDL + lcol) * C::ES);
+  const unsigned lds0 = (unsigned)(size_t)((LDS_AS const char *)lds_raw);
+  const unsigned q_lane_off = (unsigned)((C::SLAB + wave * 16 + lcol) * C::ES);
 
-  double preg[4] = {0.0, 0.0, 0.0, 0.0};
+  T preg[4] = {0, 0, 0, 0};
   int buf = 0;
   auto load_p = [&](long long ab) {
     // P[16ab + 4q + krow, col]: inline-asm load with its own wait (once per S units)
@@ -201,61 +251,48 @@ __global__ void __launch_bounds__(512, 2) mttkrp3_kernel(const MttkrpArgs a) {
     for (int q = 0; q < 4; ++q) {
       const int arow = (int)(16 * ab) + 4 * q + krow;
       const bool ok = (arow < a.A) && cvalid;
-      const double *ptr = a.P + (ok ? arow + a.ldP * col : 0);
-      double v;
-      asm volatile("global_load_dwordx2 %0, %1, off\n\ts_waitcnt vmcnt(0)"
-                   : "=&v"(v)
-                   : "v"(ptr)
-                   : "memory");
-      preg[q] = ok ? v : 0.0;
+      const T *ptr = Pm + (ok ? arow + a.ldP * col : 0);
+      T v;
+      if constexpr (C::ES == 8)
+        asm volatile("global_load_dwordx2 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(ptr) : "memory");
+      else
+        asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(ptr) : "memory");
+      preg[q] = ok ? v : (T)0;
     }
   };
 
-  // Stagger (MI355X_MICROARCH "Two waves per SIMD", item 9): the two waves of a SIMD run the same
-  // program; with the barrier at the same program point they stay in lockstep and hit their
-  // slab-switch bubble (Q read + ring refill, ~250 cycles) together.  Waves 0-3 therefore take
-  // the stage's barrier in the MIDDLE of a slab, waves 4-7 at the START of the same slab: the
-  // invariants hold for both (see header), and one half is always in full MFMA flow while the
-  // other refills.
-  unsigned long long dbg_bar = 0, dbg_top = 0, dbg_half1 = 0, dbg_half2 = 0;
   auto unit_loop = [&]<bool LATE>() {
     long long ab_loaded = -1;
     for (long long iu = 0; iu < n_units; ++iu) {
       const int buf_n = (buf == 2) ? 0 : buf + 1;
       const int buf_nn = (buf_n == 2) ? 0 : buf_n + 1;
-      const unsigned base = lds0 + (unsigned)(buf * C::BUF * 8) + lane_off;
+      const unsigned base = lds0 + (unsigned)(buf * C::BUF * C::ES) + lane_off;
       const bool fetch = (iu + 2 < n_units) && !DIAG(a.dbg_no_dma);
-      const double *src_slab = a.Xp + (long long)a.Mp * (16 * ab_2) + slab_stride_s * s_2;
-      const double *q_row = a.Q + s_2;
-      double *dst = lds + buf_nn * C::BUF;
+      const T *src_slab = Xp + (long long)a.Mp * (16 * ab_2) + slab_stride_s * s_2;
+      const T *q_row = Qm + s_2;
+      T *dst = lds + buf_nn * C::BUF;
 
       if constexpr (LATE) {
         // barrier #iu at the start of slab iu: DMA(iu+1) landed everywhere; slab iu-1 is finished
         // by everybody (waves 0-3 are in the middle of slab iu), so DMA(iu+2) may overwrite it
-        const unsigned long long s0 = DIAG(a.dbg_clock) ? __builtin_amdgcn_s_memtime() : 0ull;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (!DIAG(a.dbg_no_barrier)) __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        if (DIAG(a.dbg_clock)) dbg_bar += __builtin_amdgcn_s_memtime() - s0;
       }
-      const unsigned long long st0 = DIAG(a.dbg_clock) ? __builtin_amdgcn_s_memtime() : 0ull;
       if (ab_c != ab_loaded) {
         load_p(ab_c);
         ab_loaded = ab_c;
       }
-      // Q of this slab, then the first D operands (ring local to the stage: no in-flight
-      // inline-asm load is live across the loop back-edge)
-      double ring[C::D];
-      double qcur;
-      asm volatile("ds_read_b64 %0, %1" : "=v"(qcur) : "v"(lds0 + (unsigned)(buf * C::BUF * 8) + q_lane_off));
+      // Q of this slab, then the first D operands (ring local to the stage)
+      T ring[C::D];
+      T qcur;
+      lds_read<T>(qcur, lds0 + (unsigned)(buf * C::BUF * C::ES) + q_lane_off);
       P3::template preload<0>(ring, base);
       asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(C::D));  // Q landed (D younger reads in flight)
       __builtin_amdgcn_sched_barrier(0);
-      double bq[4];
+      T bq[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) bq[q] = preg[q] * qcur;
-      const unsigned long long st1 = DIAG(a.dbg_clock) ? __builtin_amdgcn_s_memtime() : 0ull;
-      if (DIAG(a.dbg_clock)) dbg_top += st1 - st0;
 
       // ---- first half (LATE: DMA(iu+2) one piece per MFMA step) ----
       [&]<int... Is>(std::integer_sequence<int, Is...>) {
@@ -269,16 +306,12 @@ __global__ void __launch_bounds__(512, 2) mttkrp3_kernel(const MttkrpArgs a) {
             ...);
       }(std::make_integer_sequence<int, C::H>{});
 
-      const unsigned long long st2 = DIAG(a.dbg_clock) ? __builtin_amdgcn_s_memtime() : 0ull;
-      if (DIAG(a.dbg_clock)) dbg_half1 += st2 - st1;
       if constexpr (!LATE) {
         // barrier #iu in the middle of slab iu (same invariants)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (!DIAG(a.dbg_no_barrier)) __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        if (DIAG(a.dbg_clock)) dbg_bar += __builtin_amdgcn_s_memtime() - st2;
       }
-      const unsigned long long st3 = DIAG(a.dbg_clock) ? __builtin_amdgcn_s_memtime() : 0ull;
 
       // ---- second half (!LATE: DMA(iu+2) one piece per MFMA step) ----
       [&]<int... Is>(std::integer_sequence<int, Is...>) {
@@ -292,7 +325,6 @@ __global__ void __launch_bounds__(512, 2) mttkrp3_kernel(const MttkrpArgs a) {
             ...);
       }(std::make_integer_sequence<int, C::N - C::H>{});
 
-      if (DIAG(a.dbg_clock)) dbg_half2 += __builtin_amdgcn_s_memtime() - st3;
       buf = buf_n;
       ab_c = ab_1;
       s_c = s_1;
@@ -302,57 +334,61 @@ __global__ void __launch_bounds__(512, 2) mttkrp3_kernel(const MttkrpArgs a) {
       if (s_2 >= S) { s_2 = 0; ab_2++; }
     }
   };
-  if (DIAG(a.dbg_prio == 1) && wave >= 4) __builtin_amdgcn_s_setprio(1);
-  if (DIAG(a.dbg_prio == 2) && wave < 4) __builtin_amdgcn_s_setprio(1);
+  // DMA pieces ride on the MFMA steps of one half of a slab: the half must have NP + 1 of them
+  static_assert(C::NP + 1 <= C::H && C::NP + 1 <= C::N - C::H, "slab too short for its DMA pieces");
   if (wave < 4 || DIAG(a.dbg_no_stagger))
     unit_loop.template operator()<false>();
   else
     unit_loop.template operator()<true>();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-  if (DIAG(a.dbg_clock) && lane == 0) {
+  if (DIAG(a.dbg_clock) && tid == 0) {
     const int wg = blockIdx.x + gridDim.x * blockIdx.y;
-    if (wave == 0) {
-      a.dbg_clock[2 * wg] = __builtin_amdgcn_s_memtime() - dbg_t0;
-      a.dbg_clock[2 * wg + 1] = __builtin_amdgcn_s_memrealtime() - dbg_r0;
-    }
-    if (wg < 32) {
-      unsigned long long *o = a.dbg_clock + 8192 + (wg * 8 + wave) * 5;
-      o[0] = dbg_bar; o[1] = dbg_top; o[2] = dbg_half1; o[3] = dbg_half2; o[4] = (unsigned long long)n_units;
-    }
+    a.dbg_clock[2 * wg] = __builtin_amdgcn_s_memtime() - dbg_t0;
+    a.dbg_clock[2 * wg + 1] = __builtin_amdgcn_s_memrealtime() - dbg_r0;
   }
 
   // ---- epilogue: partial tile [ldPart x 128] of (nb, tm)
-  double *pt = a.partial + ((long long)(nb * a.T + tm)) * ((long long)a.ldPart * CALS_BN);
+  T *pt = static_cast<T *>(a.partial) + ((long long)(nb * a.T + tm)) * ((long long)a.ldPart * CALS_BN);
   const int cl = wave * 16 + lcol;
 #pragma unroll
   for (int t = 0; t < MT; ++t) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int m = m0 + 16 * t + krow + 4 * r;
+      const int m = m0 + 16 * t + Acc<T>::row(krow, r);
       pt[m + (long long)a.ldPart * cl] = acc[t][r];
     }
   }
 }
 
-template <int MT>
+template <int MT, typename T>
 static hipError_t launch3_mt(int m_blocks, const MttkrpArgs &a, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&mttkrp3_kernel<MT>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&mttkrp3_kernel<MT, T>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       Mt3Cfg<MT>::LDS_BYTES);
+                                       Mt3Cfg<MT, T>::LDS_BYTES);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
   dim3 grid(a.grid, m_blocks, 1), block(512, 1, 1);
-  hipLaunchKernelGGL(mttkrp3_kernel<MT>, grid, block, Mt3Cfg<MT>::LDS_BYTES, st, a);
+  constexpr int lds_bytes = Mt3Cfg<MT, T>::LDS_BYTES;
+  hipLaunchKernelGGL((mttkrp3_kernel<MT, T>), grid, block, lds_bytes, st, a);
   return hipGetLastError();
 }
 
 hipError_t mttkrp3_launch(int MT, int m_blocks, const MttkrpArgs &a, hipStream_t st) {
+  if (a.dtype == CALS_F32) {
+    switch (MT) {
+#define CASE(N) case N: return launch3_mt<N, float>(m_blocks, a, st);
+      CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(10) CASE(12) CASE(14)
+      CASE(16) CASE(19) CASE(20)
+#undef CASE
+    }
+    return hipErrorInvalidValue;
+  }
   switch (MT) {
-#define CASE(N) case N: return launch3_mt<N>(m_blocks, a, st);
+#define CASE(N) case N: return launch3_mt<N, double>(m_blocks, a, st);
     CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(10) CASE(12) CASE(14)
     CASE(16) CASE(19) CASE(20)
 #undef CASE

@@ -88,6 +88,17 @@ void cals_hip_default_params(cals_hip_params *p);
  * (columns of every multi-factor).  device = HIP ordinal. */
 int cals_hip_create(cals_hip_engine **out, int n_modes, const int64_t *modes, int64_t buffer_size,
                     int device);
+/* Same, with the STORAGE (= arithmetic) type of the tensor copies, the multi-factors and the MTTKRP
+ * on the device: CALS_HIP_F64 (the reference's only type, v_mfma_f64_16x16x4_f64) or CALS_HIP_F32
+ * (BASELINE config 4: v_mfma_f32_16x16x4_f32, fp32 accumulate).  In fp32 mode the per-model
+ * Gramians, Cholesky, solves' accumulators, lambda, error and fit stay fp64; factors cross this ABI
+ * as doubles either way (rounded to fp32 once, on admission).  There is no reference counterpart:
+ * the reference is fp64 throughout (include/matrix.h:26, `double *data`). */
+#define CALS_HIP_F64 0
+#define CALS_HIP_F32 1
+int cals_hip_create_ex(cals_hip_engine **out, int n_modes, const int64_t *modes,
+                       int64_t buffer_size, int device, int dtype);
+int cals_hip_dtype(const cals_hip_engine *e);
 int cals_hip_destroy(cals_hip_engine *e);
 const char *cals_hip_last_error(const cals_hip_engine *e);
 
@@ -96,6 +107,8 @@ const char *cals_hip_last_error(const cals_hip_engine *e);
  * X_host: prod(modes) doubles, mode 0 fastest (include/tensor.h:173).  The engine keeps one
  * zero-padded permuted copy per mode in HBM (layout: DESIGN.md). */
 int cals_hip_set_tensor(cals_hip_engine *e, const double *X_host);
+/* Same for a tensor held in fp32 on the host (any engine dtype; an F64 engine widens it). */
+int cals_hip_set_tensor_f32(cals_hip_engine *e, const float *X_host);
 
 int cals_hip_set_params(cals_hip_engine *e, const cals_hip_params *p);
 
