@@ -144,13 +144,30 @@ def main():
 
     value, t_max = sharding.aggregate_rate(args.steps, elapsed, device=red_dev)
     ks = eng.kernel_stats()
+    plan = eng.tree
     eng.set_profiling(False)
 
     out = None
     if rank == 0:
-        avg_ms = ks.mttkrp_ms / max(ks.mttkrp_launches, 1)
-        flops_per_launch = ks.mttkrp_flops / max(ks.mttkrp_launches, 1)
-        achieved = flops_per_launch / (avg_ms * 1e-3) * 1e-12 if avg_ms > 0 else 0.0
+        # the two MFMA kernels of a sweep: the fused MTTKRP and (dimension-tree plans) the TTM that
+        # replaces two of the three MTTKRPs; both do 2*prod(modes)*R algorithmic flops per launch
+        kern = {}
+        for name, n, ms, fl in (("mttkrp3_kernel (fused MTTKRP)", ks.mttkrp_launches, ks.mttkrp_ms, ks.mttkrp_flops),
+                                ("ttm_kernel (TTM shared by two modes + fused G)", ks.ttm_launches, ks.ttm_ms, ks.ttm_flops)):
+            if n:
+                kern[name] = {"launches": n, "avg_launch_ms": round(ms / n, 4), "total_ms": round(ms, 3),
+                              "flops_per_launch": fl / n,
+                              "achieved_tflops": round(fl / n / (ms / n * 1e-3) * 1e-12, 3)}
+        dom = max(kern, key=lambda k: kern[k]["total_ms"])
+        avg_ms = kern[dom]["avg_launch_ms"]
+        flops_per_launch = kern[dom]["flops_per_launch"]
+        achieved = kern[dom]["achieved_tflops"]
+        contract = None
+        if ks.contract_launches:
+            contract = {"launches": ks.contract_launches,
+                        "avg_launch_ms": round(ks.contract_ms / ks.contract_launches, 4),
+                        "achieved_GBps": round(ks.contract_bytes / (ks.contract_ms * 1e-3) * 1e-9, 1),
+                        "bound": "hbm", "peak_GBps": 8000}
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
@@ -168,12 +185,15 @@ def main():
                                        k_models, R, "on" if ls else "off", world),
                        "name": args.workload, "models_per_gpu": k_models, "total_models": k_models * world,
                        "sharding": "model m -> GPU m mod N, X replicated, no data-path collective"},
-            "roofline": {"bound": "mfma", "kernel": "mttkrp3_kernel (fused MTTKRP, v_mfma_%s)" % (
-                             "f32_16x16x4_f32" if dtype == "f32" else "f64_16x16x4_f64"),
+            "roofline": {"bound": "mfma", "kernel": "%s, v_mfma_%s" % (
+                             dom, "f32_16x16x4_f32" if dtype == "f32" else "f64_16x16x4_f64"),
                          "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4), "traffic": traffic,
                          "flops_per_launch": flops_per_launch, "avg_launch_ms": round(avg_ms, 4),
-                         "launches": ks.mttkrp_launches,
+                         "launches": kern[dom]["launches"],
+                         "plan": {0: "3 fused MTTKRPs per sweep", 1: "dimension tree A (modes 0,1 share X x_2 C)",
+                                  2: "dimension tree B (modes 1,2 share X x_0 A)"}[plan],
+                         "mfma_kernels": kern, "contract_kernel": contract,
                          "other_kernels_ms_per_step": round((ks.update_ms + ks.other_ms) / args.steps, 4)},
         }
     eng.close()

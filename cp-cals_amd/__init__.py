@@ -51,6 +51,8 @@ class KernelStats(C.Structure):
         ("mttkrp_launches", C.c_int64), ("mttkrp_ms", C.c_double), ("mttkrp_flops", C.c_double),
         ("update_launches", C.c_int64), ("update_ms", C.c_double),
         ("other_launches", C.c_int64), ("other_ms", C.c_double),
+        ("ttm_launches", C.c_int64), ("ttm_ms", C.c_double), ("ttm_flops", C.c_double),
+        ("contract_launches", C.c_int64), ("contract_ms", C.c_double), ("contract_bytes", C.c_double),
     ]
 
 
@@ -65,7 +67,7 @@ EXPORTS = [
     "cals_hip_debug_get_lambda", "cals_hip_debug_get_gramian", "cals_hip_debug_model_status",
     "cals_hip_debug_get_norms", "cals_hip_set_profiling", "cals_hip_get_kernel_stats",
     "cals_hip_reset_kernel_stats", "cals_hip_stream", "cals_hip_device_count",
-    "cals_hip_create_ex", "cals_hip_dtype", "cals_hip_set_tensor_f32",
+    "cals_hip_create_ex", "cals_hip_dtype", "cals_hip_tree", "cals_hip_set_tensor_f32",
     "cals_hip_debug_clock", "cals_hip_host_first_fit", "cals_hip_host_compress_plan", "cals_hip_host_active_cols",
 ]
 
@@ -85,6 +87,7 @@ def load_library():
     lib.cals_hip_create.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(i64), i64, C.c_int]
     lib.cals_hip_create_ex.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(i64), i64, C.c_int, C.c_int]
     lib.cals_hip_dtype.argtypes = [vp]
+    lib.cals_hip_tree.argtypes = [vp]
     lib.cals_hip_set_tensor_f32.argtypes = [vp, C.POINTER(C.c_float)]
     lib.cals_hip_destroy.argtypes = [vp]
     lib.cals_hip_last_error.argtypes = [vp]
@@ -270,6 +273,11 @@ class Engine:
     @property
     def models_in_flight(self):
         return self.lib.cals_hip_models_in_flight(self.h)
+
+    @property
+    def tree(self):
+        """0 = three fused MTTKRPs per sweep, 1 = dimension tree A, 2 = tree B (cals_hip_tree)."""
+        return int(self.lib.cals_hip_tree(self.h))
 
     @property
     def queue_size(self):

@@ -46,6 +46,16 @@ struct ModeLayout {
   int MT2 = 0, m_blocks2 = 1, k_big2 = 0;      // v2 tiling (two 4-wave workgroups per CU)
 };
 
+// Dimension-tree pair for 3-way tensors (ttm_kernel.hip): modes `first` and `second` (consecutive
+// in the sweep) share T = X x_a P; the remaining mode runs the plain fused MTTKRP.
+struct TreePlan {
+  bool on = false;
+  int first = 0, second = 1, a = 2;
+  int MT = 0, m_blocks = 1, k_big = 1;
+  void *Tbuf = nullptr;  // T[c][s][m]: buffer x S x Mp elements
+  void *Pt = nullptr;    // packed factor of mode a: [NB][Ap][CALS_BN]
+};
+
 struct EventPair {
   hipEvent_t a, b;
 };
@@ -74,6 +84,7 @@ struct cals_hip_engine {
   double *d_jk_norms = nullptr;
   std::vector<double> jk_norms;
   ModeLayout lay[CALS_HIP_MAX_MODES];
+  TreePlan tree;
 
   int dtype = CALS_F64;  // storage type of X copies, multi-factors, partials (compute follows it)
   size_t es = sizeof(double);
@@ -116,7 +127,7 @@ struct cals_hip_engine {
   std::vector<EventPair> ev_pool;
   size_t ev_used = 0;
   struct Rec {
-    int cls;  // 0 mttkrp, 1 update, 2 other
+    int cls;  // 0 mttkrp, 1 update, 2 other, 3 ttm (flops), 4 contract (flops field = bytes)
     size_t ev;
     double flops;
   };
@@ -239,6 +250,14 @@ void prof_collect(cals_hip_engine *e) {
     } else if (r.cls == 1) {
       e->stats.update_launches++;
       e->stats.update_ms += ms;
+    } else if (r.cls == 3) {
+      e->stats.ttm_launches++;
+      e->stats.ttm_ms += ms;
+      e->stats.ttm_flops += r.flops;
+    } else if (r.cls == 4) {
+      e->stats.contract_launches++;
+      e->stats.contract_ms += ms;
+      e->stats.contract_bytes += r.flops;
     } else {
       e->stats.other_launches++;
       e->stats.other_ms += ms;
@@ -365,6 +384,70 @@ int launch_mttkrp(cals_hip_engine *e, int mode, int64_t R, Geo *geo_out) {
   return CALS_HIP_OK;
 }
 
+// TTM of the tree pair: T = X x_a P (to HBM) and the partial tiles of G_first
+Geo tree_geometry(const cals_hip_engine *e, int64_t R) {
+  const TreePlan &tp = e->tree;
+  Geo g;
+  g.NB = (int)((R + CALS_BN - 1) / CALS_BN);
+  long long T = e->n_cu / std::max(1, g.NB * tp.m_blocks);
+  if (T < 1) T = 1;
+  if (T > e->modes[tp.second]) T = e->modes[tp.second];
+  g.T = (int)T;
+  return g;
+}
+
+int launch_ttm(cals_hip_engine *e, int64_t R, Geo *geo_out) {
+  const TreePlan &tp = e->tree;
+  const ModeLayout &L = e->lay[tp.first];
+  const Geo g = tree_geometry(e, R);
+  {
+    const int pk = prof_begin(e, 2, 0);
+    HIPCHK(pack_pt_launch(e->factor[tp.a], e->modes[tp.a], L.A, L.Ap, g.NB, (int)R, tp.Pt, e->dtype,
+                          e->stream));
+    prof_end(e, pk);
+  }
+  TtmArgs a{};
+  a.Xp = L.Xp;
+  a.Pt = tp.Pt;
+  a.Q = e->factor[tp.second];
+  a.ldQ = e->modes[tp.second];
+  a.partial = e->partial;
+  a.Tout = tp.Tbuf;
+  a.dtype = e->dtype;
+  a.S = L.S;
+  a.Mp = L.Mp;
+  a.Ap = L.Ap;
+  a.R = (int)R;
+  a.NB = g.NB;
+  a.T = g.T;
+  a.ldPart = L.ldPart;
+  a.grid = g.NB * g.T;
+  a.m_blocks = tp.m_blocks;
+  a.k_big = tp.k_big;
+  a.MT = tp.MT;
+  if ((size_t)g.NB * g.T * (size_t)L.ldPart * CALS_BN > e->partial_elems)
+    return fail(e, CALS_HIP_ERR_STATE, "internal: partial buffer too small");
+  double total = 1.0;
+  for (int n = 0; n < e->n_modes; n++) total *= (double)e->modes[n];
+  const int pk = prof_begin(e, 3, 2.0 * total * (double)R);
+  HIPCHK(ttm_launch(a, e->stream));
+  prof_end(e, pk);
+  if (geo_out) *geo_out = g;
+  return CALS_HIP_OK;
+}
+
+// G_second[s, c] = sum_m T[m, s, c] F_first[m, c], written to `out` (ld = I_second)
+int launch_contract(cals_hip_engine *e, int64_t R, void *out) {
+  const TreePlan &tp = e->tree;
+  const ModeLayout &L = e->lay[tp.first];
+  const double bytes = (double)R * (double)L.S * (double)L.Mp * (double)e->es;
+  const int pk = prof_begin(e, 4, bytes);
+  HIPCHK(contract_launch(tp.Tbuf, L.S, L.Mp, (int)e->modes[tp.first], e->factor[tp.first],
+                         e->modes[tp.first], out, e->modes[tp.second], (int)R, e->dtype, e->stream));
+  prof_end(e, pk);
+  return CALS_HIP_OK;
+}
+
 LsArgs make_ls_args(cals_hip_engine *e) {
   LsArgs a{};
   a.slots = e->d_slots;
@@ -403,8 +486,15 @@ int sweep_once(cals_hip_engine *e, bool evict_enabled) {
     prof_end(e, pk);
   }
   for (int n = 0; n < e->n_modes; n++) {
-    Geo g;
-    if ((rc = launch_mttkrp(e, n, R, &g))) return rc;
+    Geo g{0, 0};
+    const bool by_contract = e->tree.on && n == e->tree.second;
+    if (by_contract) {
+      if ((rc = launch_contract(e, R, e->factor[n]))) return rc;
+    } else if (e->tree.on && n == e->tree.first) {
+      if ((rc = launch_ttm(e, R, &g))) return rc;
+    } else if ((rc = launch_mttkrp(e, n, R, &g))) {
+      return rc;
+    }
     UpdateArgs u{};
     u.slots = e->d_slots;
     u.n_slots = ns;
@@ -424,8 +514,9 @@ int sweep_once(cals_hip_engine *e, bool evict_enabled) {
     u.X_norm = e->X_norm;
     u.jk_norms = e->d_jk_norms;
     const int pk = prof_begin(e, 1, 0);
-    HIPCHK(reduce_partials_launch(e->partial, g.T, e->lay[n].ldPart, (int)e->modes[n], (int)R,
-                                  e->factor[n], e->dtype, e->stream));
+    if (!by_contract)
+      HIPCHK(reduce_partials_launch(e->partial, g.T, e->lay[n].ldPart, (int)e->modes[n], (int)R,
+                                    e->factor[n], e->dtype, e->stream));
     HIPCHK(update_launch(u, CALS_RMAX, e->stream));
     prof_end(e, pk);
   }
@@ -740,19 +831,68 @@ int cals_hip_create_ex(cals_hip_engine **out, int n_modes, const int64_t *modes,
   cals_hip_default_params(&e->prm);
   HIPCHK(hipStreamCreate(&e->stream));
 
-  // layouts: inner mode a = the remaining mode with the least padding waste
-  size_t part_rows_max = 0, krp_max = 0;
-  for (int n = 0; n < n_modes; n++) {
-    ModeLayout &L = e->lay[n];
+  // inner mode a of the plain MTTKRP = the remaining mode with the least padding waste
+  auto pick_a = [&](int n) {
     double best = 1e30;
+    int a_mode = -1;
     for (int k = 0; k < n_modes; k++) {
       if (k == n) continue;
       const double waste = (double)round_up((int)modes[k], 16) / (double)modes[k];
       if (waste < best - 1e-12) {
         best = waste;
-        L.a_mode = k;
+        a_mode = k;
       }
     }
+    return a_mode;
+  };
+  // ---- dimension tree (3-way only): CALS_HIP_TREE = 0 | A | B, default: cost model ----
+  if (n_modes == 3) {
+    const double peak = (e->dtype == CALS_F32) ? 157.3e12 * 0.8 : 78.6e12 * 0.9;
+    auto eff = [](int mt) { return (double)mt / ((double)mt + 1.0); };  // fitted to measured MT sweeps
+    auto plain_cost = [&](int n) {  // seconds per column of the multi-factor
+      const int a_mode = pick_a(n);
+      const int tiles = round_up((int)modes[n], 16) / 16;
+      const int mb = (tiles + 19) / 20;
+      const int mt = mttkrp_pick_mt((tiles + mb - 1) / mb);
+      const double S = (double)modes[3 - n - a_mode];
+      return 2.0 * 16.0 * mb * mt * round_up((int)modes[a_mode], 16) * S / (peak * eff(mt));
+    };
+    auto tree_cost = [&](int first, int second, int a_mode) {
+      const int Mp = round_up((int)modes[first], 16), tiles = Mp / 16;
+      const int mb = (tiles + ttm_max_mt(e->dtype) - 1) / ttm_max_mt(e->dtype);
+      const int mt = (tiles + mb - 1) / mb;
+      const double S = (double)modes[second];
+      const double ttm = 2.0 * Mp * round_up((int)modes[a_mode], 16) * S / (peak * eff(mt) * 0.97);
+      const double t_bytes = (double)Mp * S * (double)e->es;
+      return ttm + 1.3 * t_bytes / 3.5e12 + plain_cost(a_mode);
+    };
+    const double c_plain = plain_cost(0) + plain_cost(1) + plain_cost(2);
+    const double c_a = tree_cost(0, 1, 2), c_b = tree_cost(1, 2, 0);
+    int choice = 0;  // 0 off, 1 = A (modes 0,1 share X x_2 C), 2 = B (modes 1,2 share X x_0 A)
+    if (std::min(c_a, c_b) < 0.97 * c_plain) choice = (c_a <= c_b) ? 1 : 2;
+    if (const char *v = getenv("CALS_HIP_TREE")) {
+      if (v[0] == '0') choice = 0;
+      else if (v[0] == 'A' || v[0] == 'a' || v[0] == '1') choice = 1;
+      else if (v[0] == 'B' || v[0] == 'b' || v[0] == '2') choice = 2;
+    }
+    if (choice) {
+      TreePlan &tp = e->tree;
+      tp.first = (choice == 1) ? 0 : 1;
+      tp.second = tp.first + 1;
+      tp.a = (choice == 1) ? 2 : 0;
+      const size_t t_bytes = (size_t)buffer_size * (size_t)modes[tp.second] *
+                             (size_t)round_up((int)modes[tp.first], 16) * e->es;
+      size_t free_b = 0, total_b = 0;
+      HIPCHK(hipMemGetInfo(&free_b, &total_b));
+      tp.on = t_bytes < free_b / 3;  // T must leave room for X copies and the model state
+    }
+  }
+
+  // layouts
+  size_t part_rows_max = 0, krp_max = 0;
+  for (int n = 0; n < n_modes; n++) {
+    ModeLayout &L = e->lay[n];
+    L.a_mode = (e->tree.on && n == e->tree.first) ? e->tree.a : pick_a(n);
     L.A = (int)modes[L.a_mode];
     L.Ap = round_up(L.A, 16);
     L.Mp = round_up((int)modes[n], 16);
@@ -763,7 +903,9 @@ int cals_hip_create_ex(cals_hip_engine **out, int n_modes, const int64_t *modes,
         L.S *= modes[k];
       }
     const int m_tiles = L.Mp / 16;
-    L.m_blocks = (m_tiles + 19) / 20;
+    int max_mt = 20;  // CALS_MTTKRP_MAX_MT: experiments with more, shorter M blocks
+    if (const char *v = getenv("CALS_MTTKRP_MAX_MT")) max_mt = std::min(20, std::max(1, atoi(v)));
+    L.m_blocks = (m_tiles + max_mt - 1) / max_mt;
     L.MT = mttkrp_pick_mt((m_tiles + L.m_blocks - 1) / L.m_blocks);
     if (L.MT == 0) return fail(e, CALS_HIP_ERR_ARG, "internal: no MTTKRP tile for this mode size");
     L.ldPart = L.m_blocks * 16 * L.MT;
@@ -780,6 +922,16 @@ int cals_hip_create_ex(cals_hip_engine **out, int n_modes, const int64_t *modes,
   }
   if ((rc = dev_alloc(e, &e->lambda, (size_t)buffer_size))) return rc;
   const size_t nb_max = (size_t)((buffer_size + CALS_BN - 1) / CALS_BN);
+  if (e->tree.on) {
+    TreePlan &tp = e->tree;
+    const ModeLayout &L = e->lay[tp.first];
+    const int tiles = L.Mp / 16, max_mt = ttm_max_mt(e->dtype);
+    tp.m_blocks = (tiles + max_mt - 1) / max_mt;
+    tp.MT = (tiles + tp.m_blocks - 1) / tp.m_blocks;
+    tp.k_big = tiles - tp.m_blocks * (tp.MT - 1);
+    if ((rc = dev_alloc_elems(e, &tp.Pt, nb_max * (size_t)L.Ap * CALS_BN))) return rc;
+    HIPCHK(hipMalloc(&tp.Tbuf, (size_t)buffer_size * (size_t)L.S * (size_t)L.Mp * e->es));
+  }
   size_t ld_max = 0;
   for (int n = 0; n < n_modes; n++) ld_max = std::max<size_t>(ld_max, (size_t)e->lay[n].ldPart);
   e->partial_elems = std::max<size_t>((size_t)2 * e->n_cu, nb_max) * ld_max * CALS_BN;
@@ -846,6 +998,8 @@ int cals_hip_destroy(cals_hip_engine *e) {
   fr(e->prev_lambda);
   fr(e->backup_lambda);
   fr(e->partial);
+  fr(e->tree.Tbuf);
+  fr(e->tree.Pt);
   fr(e->krp_ws);
   fr(e->d_jk_norms);
   fr(e->mt.col);
@@ -932,6 +1086,11 @@ int cals_hip_set_tensor(cals_hip_engine *e, const double *X_host) {
 
 int cals_hip_set_tensor_f32(cals_hip_engine *e, const float *X_host) {
   return set_tensor_impl(e, X_host, CALS_F32);
+}
+
+int cals_hip_tree(const cals_hip_engine *e) {
+  if (!e || !e->tree.on) return 0;
+  return e->tree.first == 0 ? 1 : 2;
 }
 
 int cals_hip_dtype(const cals_hip_engine *e) {
@@ -1061,7 +1220,27 @@ int cals_hip_debug_mttkrp(cals_hip_engine *e, int mode, double *G_host) {
   if (e->registry.empty()) return fail(e, CALS_HIP_ERR_STATE, "no model in flight");
   const int64_t R = e->end;
   Geo g;
-  int rc = launch_mttkrp(e, mode, R, &g);
+  int rc;
+  if (e->tree.on && mode == e->tree.second) {
+    // through the tree pair: T from the current factors, then the contraction into a scratch buffer
+    const int64_t I = e->modes[mode];
+    if ((rc = launch_ttm(e, R, &g))) return rc;
+    void *scratch = nullptr;
+    HIPCHK(hipMalloc(&scratch, (size_t)(I * R) * e->es));
+    if ((rc = launch_contract(e, R, scratch))) return rc;
+    std::vector<float> hf;
+    if (e->dtype == CALS_F32) hf.resize((size_t)(I * R));
+    HIPCHK(hipMemcpyAsync(e->dtype == CALS_F32 ? (void *)hf.data() : (void *)G_host, scratch,
+                          (size_t)(I * R) * e->es, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    for (size_t i = 0; i < hf.size(); i++) G_host[i] = (double)hf[i];
+    HIPCHK(hipFree(scratch));
+    return CALS_HIP_OK;
+  }
+  if (e->tree.on && mode == e->tree.first)
+    rc = launch_ttm(e, R, &g);
+  else
+    rc = launch_mttkrp(e, mode, R, &g);
   if (rc) return rc;
   const ModeLayout &L = e->lay[mode];
   const size_t tile = (size_t)L.ldPart * CALS_BN;

@@ -49,6 +49,32 @@ hipError_t mttkrp2_launch(int MT, const MttkrpArgs &a, hipStream_t st);
 // v3 schedule (mttkrp_kernel_v3.hip): v1's tiling, 3-buffer ring, mid-stage barrier
 hipError_t mttkrp3_launch(int MT, int m_blocks, const MttkrpArgs &a, hipStream_t st);
 
+// ---------------------------------------------------------------------------------------------
+// Dimension-tree pair (ttm_kernel.hip): T[m,s,c] = sum_a Xp[m,a,s] P[a,c];
+// G_first[m,c] = sum_s T Q[s,c] (fused); G_second[s,c] = sum_m T F[m,c] (contract)
+// ---------------------------------------------------------------------------------------------
+struct TtmArgs {
+  const void *Xp;    // [Mp][Ap][S] permuted padded copy of mode `first` with a = the third mode
+  const void *Pt;    // packed factor of mode a: [NB][Ap][CALS_BN], zero padded (pack_pt_launch)
+  const void *Q;     // factor of mode s (= `second`), S x R, ld = ldQ
+  void *partial;     // G_first partial tiles: [NB*T] of ldPart x CALS_BN
+  void *Tout;        // T[c][s][m], m fastest, pitch Mp
+  int dtype;
+  long long S, ldQ;
+  int Mp, Ap, R;
+  int NB, T;         // column blocks, team size (workgroups per column block and M block; split s)
+  int ldPart;
+  int grid;          // NB * T
+  int m_blocks, k_big, MT;  // M blocks: the first k_big are MT tiles high, the others MT - 1
+};
+int ttm_max_mt(int dtype);
+hipError_t ttm_launch(const TtmArgs &a, hipStream_t st);
+hipError_t pack_pt_launch(const void *P, long long ldP, int A, int Ap, int NB, int R, void *Pt,
+                          int dtype, hipStream_t st);
+hipError_t contract_launch(const void *Tb, long long S, int Mp, int M, const void *F,
+                           long long ldF, void *out, long long ldOut, int R, int dtype,
+                           hipStream_t st);
+
 // Q[s,c] for N > 3: Khatri-Rao of the streamed modes' factors (first streamed mode fastest)
 struct KrpArgs {
   const void *F[CALS_MAX_MODES];  // element type = dtype

@@ -1,0 +1,473 @@
+// Dimension-tree pair of MTTKRPs for 3-way tensors on gfx950 (fp64 and fp32 storage).
+//
+// Two consecutive modes of a sweep share the contraction of X with the factor that neither of them
+// updates (the reference's two-step MTTKRP, src/utils/mttkrp.cpp:330-560, applied to the whole
+// multi-factor block and shared between two modes):
+//
+//   T[m, s, c] = sum_a Xp[m, a, s] * P[a, c]                        ("TTM", the MFMA GEMM)
+//   G_first [m, c] = sum_s T[m, s, c] * Q[s, c]                     (fused here, in registers)
+//   G_second[s, c] = sum_m T[m, s, c] * F[m, c]                     (contract_kernel, HBM-bound)
+//
+// where `first` is the mode indexed by m, `second` the mode indexed by s (updated right after
+// `first` in the sweep), a the third mode, P/Q the CURRENT factors of modes a/s and F the factor of
+// mode `first` AFTER its update.  T depends on P only, which is not touched between the two modes,
+// so the second MTTKRP costs one pass over T instead of a second 2*I*J*K*R-flop GEMM.
+//
+// ttm_kernel: the wave tiling, LDS-DMA ring, staggered mid-stage barrier and counted-wait operand
+// pipeline of mttkrp_kernel_v3.hip, with three differences:
+//   * the B operand of the MFMAs is P[a, c] itself, streamed through LDS next to the X slab from a
+//     packed copy Pt[column block][a][128 columns] (pack_pt_kernel) -- a (16 x 128) tile per stage;
+//   * units run a-block fastest: a wave accumulates T[:, s, :] over all a in `tacc`, and at the end
+//     of every s adds tacc * Q[s, c] into `gacc`, stores tacc to T and clears it;
+//   * a workgroup team splits the s range (never the a range), so T needs no cross-workgroup
+//     reduction; G_first partials go through the same partial tiles + reduce_partials_kernel as the
+//     plain MTTKRP.
+// Two accumulator sets bound the tile height: MT <= 10 m-tiles in fp64, <= 20 in fp32; taller modes
+// are cut into M blocks (blockIdx.y), the first k_big of them MT tiles high, the others MT - 1.
+#include "mfma_common.h"
+
+namespace calship {
+
+template <int MT, typename T>
+struct TtmCfg {
+  static constexpr int ES = (int)sizeof(T);
+  static constexpr int LDL = (MT % 2 == 1) ? 16 * MT : 16 * MT + 16;  // elements; = 16 mod 32
+  static constexpr int SLAB = 16 * LDL;              // X slab: 16 a-rows x LDL
+  static constexpr int PE = 1024 / ES;               // elements per 1-KiB DMA piece
+  static constexpr int PIECES = SLAB / PE;
+  static constexpr int NP = (PIECES + 7) / 8;        // X pieces per wave (upper bound)
+  static constexpr int QOFF = SLAB;                  // the stage's 128 Q values
+  static constexpr int QPE = 256 / ES;               // Q elements per 4-byte-per-lane DMA piece
+  static constexpr int QPIECES = CALS_BN / QPE;      // 4 (f64) or 2 (f32)
+  static constexpr int POFF = SLAB + CALS_BN;        // P tile: 16 rows, pitch PP (= 16 mod 32)
+  static constexpr int PP = CALS_BN + 16;
+  static constexpr int PLB = (ES == 8) ? 16 : 4;     // bytes per lane of one P DMA instruction
+  static constexpr int PPE = 64 * PLB / ES;          // elements per P DMA instruction: 128 | 64
+  static constexpr int PPR = CALS_BN / PPE;          // instructions per P row: 1 | 2
+  static constexpr int NPP = 16 * PPR / 8;           // P instructions per wave: 2 | 4
+  static constexpr int BUF = POFF + 16 * PP;
+  static constexpr int LDS_BYTES = 3 * BUF * ES;
+  static constexpr int N = 4 * MT;                   // MFMAs per slab per wave
+  static constexpr int RING = (ES == 4) ? 8 : 6;
+  static constexpr int D = N < RING ? N : RING;      // operand ring depth
+  static constexpr int H = N / 2;                    // barrier position
+  static constexpr int NDMA = NP + NPP + 1;          // DMA instructions per wave per stage
+  static constexpr int HH = (H < N - H) ? H : N - H; // MFMA steps they are spread over
+};
+
+template <int MT, typename T>
+struct TtmPipe {
+  typedef TtmCfg<MT, T> C;
+  typedef typename Acc<T>::type acc_t;
+  template <int I>
+  static __device__ __forceinline__ void step(acc_t (&acc)[MT], T (&ring)[C::D], const T (&bq)[4],
+                                              unsigned base) {
+    constexpr int outstanding = (C::D - 1 < C::N - 1 - I) ? C::D - 1 : C::N - 1 - I;
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(outstanding));
+    __builtin_amdgcn_sched_barrier(0);
+    constexpr int q = I / MT, t = I % MT;
+    acc[t] = Acc<T>::mfma(ring[I % C::D], bq[q], acc[t]);
+    if constexpr (I + C::D < C::N) {
+      constexpr int qn = (I + C::D) / MT, tn = (I + C::D) % MT;
+      lds_read_off<T, ((4 * qn) * C::LDL + 16 * tn) * C::ES>(ring[I % C::D], base);
+    }
+  }
+  template <int I>
+  static __device__ __forceinline__ void preload(T (&ring)[C::D], unsigned base) {
+    if constexpr (I < C::D) {
+      constexpr int qn = I / MT, tn = I % MT;
+      lds_read_off<T, ((4 * qn) * C::LDL + 16 * tn) * C::ES>(ring[I], base);
+      preload<I + 1>(ring, base);
+    }
+  }
+};
+
+template <int MT, typename T>
+struct TtmBody {
+static __device__ __forceinline__ void run(const TtmArgs &a, const int m0, unsigned char *lds_raw) {
+  typedef TtmCfg<MT, T> C;
+  typedef TtmPipe<MT, T> P3;
+  typedef typename Acc<T>::type acc_t;
+  T *const lds = reinterpret_cast<T *>(lds_raw);
+  const T *const Xp = static_cast<const T *>(a.Xp);
+  const T *const Pt = static_cast<const T *>(a.Pt);
+  const T *const Qm = static_cast<const T *>(a.Q);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int krow = lane >> 4;
+  const int lcol = lane & 15;
+
+  // XCD-aware bijective remap (as mttkrp3_kernel): consecutive p share an XCD
+  const int G = a.grid;
+  const int b = blockIdx.x;
+  const int xcd = b & 7, q8 = G >> 3, r8 = G & 7;
+  const int p = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (b >> 3);
+  const int tm = p / a.NB;
+  const int nb = p - tm * a.NB;
+
+  const long long S = a.S;
+  const int nAb = a.Ap >> 4;
+  const long long s_begin = S * tm / a.T;
+  const long long s_end = S * (tm + 1) / a.T;
+  const long long n_units = (s_end - s_begin) * nAb;
+
+  const int col = nb * CALS_BN + wave * 16 + lcol;
+  const bool cvalid = col < a.R;
+
+  acc_t tacc[MT], gacc[MT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t) {
+    tacc[t] = (acc_t){0, 0, 0, 0};
+    gacc[t] = (acc_t){0, 0, 0, 0};
+  }
+
+  // ---- per-lane DMA source offsets (stage independent) ----
+  long long src_off[C::NP];
+#pragma unroll
+  for (int k = 0; k < C::NP; ++k) {
+    const int piece = k * 8 + wave;
+    const int e = piece * C::PE + lane * (16 / C::ES);
+    const int acol = e / C::LDL;
+    const int m = e - acol * C::LDL;
+    int gm = m0 + m;
+    gm = gm < a.Mp ? gm : 0;  // rows past the padded tensor: any valid address, unused
+    src_off[k] = gm + (long long)a.Mp * acol;
+  }
+  int p_src[C::NPP], p_dst[C::NPP];
+#pragma unroll
+  for (int k = 0; k < C::NPP; ++k) {
+    const int pp = k * 8 + wave;       // P instruction pp: row pp / PPR, columns (pp % PPR) * PPE ...
+    const int row = pp / C::PPR;
+    const int c0 = (pp % C::PPR) * C::PPE;
+    p_src[k] = row * CALS_BN + c0 + lane * (C::PLB / C::ES);
+    p_dst[k] = C::POFF + row * C::PP + c0;
+  }
+  long long q_off;
+  int q_byte;
+  {
+    const int d = wave * C::QPE + (C::ES == 8 ? (lane >> 1) : lane);
+    int c = nb * CALS_BN + d;
+    c = (c < a.R && d < CALS_BN) ? c : 0;
+    q_off = a.ldQ * c;
+    q_byte = (C::ES == 8) ? 4 * (lane & 1) : 0;
+  }
+  const long long slab_stride_s = (long long)a.Mp * a.Ap;
+  const T *const Pt_nb = Pt + (long long)nb * a.Ap * CALS_BN;
+
+  auto issue_piece = [&]<int K>(const T *src_slab, const T *p_slab, const T *q_row, T *dst) {
+    if constexpr (K < C::NP) {
+      const int piece = K * 8 + wave;
+      if (piece < C::PIECES)
+        __builtin_amdgcn_global_load_lds((const GLOBAL_AS void *)(src_slab + src_off[K]),
+                                         (LDS_AS void *)(dst + piece * C::PE), 16, 0, 0);
+    } else if constexpr (K < C::NP + C::NPP) {
+      constexpr int k = K - C::NP;
+      __builtin_amdgcn_global_load_lds((const GLOBAL_AS void *)(p_slab + p_src[k]),
+                                       (LDS_AS void *)(dst + p_dst[k]), C::PLB, 0, 0);
+    } else if (wave < C::QPIECES) {
+      const char *src = (const char *)(q_row + q_off) + q_byte;
+      __builtin_amdgcn_global_load_lds((const GLOBAL_AS void *)src,
+                                       (LDS_AS void *)(dst + C::QOFF + wave * C::QPE), 4, 0, 0);
+    }
+  };
+  // DMA instructions of MFMA step IS of the issuing half: K = IS, IS + HH, IS + 2 HH, ...
+  auto issue_at = [&]<int IS>(const T *src_slab, const T *p_slab, const T *q_row, T *dst) {
+    [&]<int... Ks>(std::integer_sequence<int, Ks...>) {
+      (
+          [&] {
+            if constexpr (Ks % C::HH == IS) issue_piece.template operator()<Ks>(src_slab, p_slab, q_row, dst);
+          }(),
+          ...);
+    }(std::make_integer_sequence<int, C::NDMA>{});
+  };
+  auto issue_all = [&](int ab, long long s, int bufi) {
+    const T *src_slab = Xp + (long long)a.Mp * (16 * ab) + slab_stride_s * s;
+    const T *p_slab = Pt_nb + (long long)(16 * ab) * CALS_BN;
+    const T *q_row = Qm + s;
+    T *dst = lds + bufi * C::BUF;
+    [&]<int... Ks>(std::integer_sequence<int, Ks...>) {
+      (issue_piece.template operator()<Ks>(src_slab, p_slab, q_row, dst), ...);
+    }(std::make_integer_sequence<int, C::NDMA>{});
+  };
+
+  int ab_c = 0;
+  long long s_c = s_begin;
+  if (n_units > 0) issue_all(ab_c, s_c, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int ab_1 = ab_c + 1;
+  long long s_1 = s_c;
+  if (ab_1 >= nAb) { ab_1 = 0; s_1++; }
+  if (n_units > 1) issue_all(ab_1, s_1, 1);
+  int ab_2 = ab_1 + 1;
+  long long s_2 = s_1;
+  if (ab_2 >= nAb) { ab_2 = 0; s_2++; }
+
+  const unsigned lane_off = (unsigned)((krow * C::LDL + lcol) * C::ES);
+  const unsigned lds0 = (unsigned)(size_t)((LDS_AS const char *)lds_raw);
+  const unsigned q_lane_off = (unsigned)((C::QOFF + wave * 16 + lcol) * C::ES);
+  const unsigned p_lane_off = (unsigned)((C::POFF + krow * C::PP + wave * 16 + lcol) * C::ES);
+  T *const Tcol = static_cast<T *>(a.Tout) + ((long long)(cvalid ? col : 0) * S) * a.Mp + m0;
+
+  // end of an s: G += T * Q[s, c]; T -> HBM; T = 0
+  auto flush = [&](long long s, T qv) {
+    T *tp = Tcol + s * a.Mp;
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) gacc[t][r] += tacc[t][r] * qv;
+      if (cvalid) {
+        if constexpr (C::ES == 4) {
+          *reinterpret_cast<acc_t *>(tp + 16 * t + 4 * krow) = tacc[t];  // rows 4 krow .. +3
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) tp[16 * t + krow + 4 * r] = tacc[t][r];
+        }
+      }
+      tacc[t] = (acc_t){0, 0, 0, 0};
+    }
+  };
+
+  int buf = 0;
+  auto unit_loop = [&]<bool LATE>() {
+    bool pend = false;       // LATE: flush of the previous unit deferred behind this unit's barrier
+    long long s_pend = 0;
+    T q_pend = 0;
+    for (long long iu = 0; iu < n_units; ++iu) {
+      const int buf_n = (buf == 2) ? 0 : buf + 1;
+      const int buf_nn = (buf_n == 2) ? 0 : buf_n + 1;
+      const unsigned bufb = lds0 + (unsigned)(buf * C::BUF * C::ES);
+      const unsigned base = bufb + lane_off;
+      const bool fetch = iu + 2 < n_units;
+      const T *src_slab = Xp + (long long)a.Mp * (16 * ab_2) + slab_stride_s * s_2;
+      const T *p_slab = Pt_nb + (long long)(16 * ab_2) * CALS_BN;
+      const T *q_row = Qm + s_2;
+      T *dst = lds + buf_nn * C::BUF;
+
+      if constexpr (LATE) {
+        // barrier #iu at the start of slab iu: DMA(iu+1) landed everywhere, slab iu-1 is finished by
+        // everybody, so DMA(iu+2) may overwrite its buffer.  The T stores of a flush are issued
+        // BEHIND this wait, so they never sit in front of it (vmcnt counts stores too).
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (pend) {
+          flush(s_pend, q_pend);
+          pend = false;
+        }
+      }
+      T ring[C::D];
+      T qcur;
+      T bq[4];
+      lds_read<T>(qcur, bufb + q_lane_off);
+      lds_read_off<T, 0>(bq[0], bufb + p_lane_off);
+      lds_read_off<T, 4 * C::PP * C::ES>(bq[1], bufb + p_lane_off);
+      lds_read_off<T, 8 * C::PP * C::ES>(bq[2], bufb + p_lane_off);
+      lds_read_off<T, 12 * C::PP * C::ES>(bq[3], bufb + p_lane_off);
+      P3::template preload<0>(ring, base);
+      asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(C::D));  // Q and P landed (D younger reads in flight)
+      __builtin_amdgcn_sched_barrier(0);
+
+      [&]<int... Is>(std::integer_sequence<int, Is...>) {
+        (
+            [&] {
+              P3::template step<Is>(tacc, ring, bq, base);
+              if constexpr (LATE && Is < C::HH) {
+                if (fetch) issue_at.template operator()<Is>(src_slab, p_slab, q_row, dst);
+              }
+            }(),
+            ...);
+      }(std::make_integer_sequence<int, C::H>{});
+
+      if constexpr (!LATE) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+      }
+
+      [&]<int... Is>(std::integer_sequence<int, Is...>) {
+        (
+            [&] {
+              P3::template step<C::H + Is>(tacc, ring, bq, base);
+              if constexpr (!LATE && Is < C::HH) {
+                if (fetch) issue_at.template operator()<Is>(src_slab, p_slab, q_row, dst);
+              }
+            }(),
+            ...);
+      }(std::make_integer_sequence<int, C::N - C::H>{});
+
+      if (ab_c == nAb - 1) {
+        if constexpr (LATE) {
+          pend = true;
+          s_pend = s_c;
+          q_pend = qcur;
+        } else {
+          flush(s_c, qcur);
+        }
+      }
+      buf = buf_n;
+      ab_c = ab_1;
+      s_c = s_1;
+      ab_1 = ab_2;
+      s_1 = s_2;
+      ab_2 = ab_2 + 1;
+      if (ab_2 >= nAb) { ab_2 = 0; s_2++; }
+    }
+    if constexpr (LATE) {
+      if (pend) flush(s_pend, q_pend);
+    }
+  };
+  if (wave < 4)
+    unit_loop.template operator()<false>();
+  else
+    unit_loop.template operator()<true>();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  // ---- epilogue: G_first partial tile [ldPart x 128] of (nb, tm)
+  T *pt = static_cast<T *>(a.partial) + ((long long)(nb * a.T + tm)) * ((long long)a.ldPart * CALS_BN);
+  const int cl = wave * 16 + lcol;
+#pragma unroll
+  for (int t = 0; t < MT; ++t) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = m0 + 16 * t + Acc<T>::row(krow, r);
+      pt[m + (long long)a.ldPart * cl] = gacc[t][r];
+    }
+  }
+}
+};
+
+template <int MT, typename T>
+__global__ void __launch_bounds__(512, 2) ttm_kernel(const TtmArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  const int by = blockIdx.y;
+  if constexpr (MT > 1) {
+    if (by >= a.k_big) {
+      TtmBody<MT - 1, T>::run(a, 16 * (a.k_big * MT + (by - a.k_big) * (MT - 1)), lds_raw);
+      return;
+    }
+  }
+  TtmBody<MT, T>::run(a, 16 * by * MT, lds_raw);
+}
+
+template <int MT, typename T>
+static hipError_t ttm_launch_mt(const TtmArgs &a, hipStream_t st) {
+  static bool attr_set = false;
+  constexpr int lds_bytes = TtmCfg<MT, T>::LDS_BYTES;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&ttm_kernel<MT, T>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  dim3 grid(a.grid, a.m_blocks, 1), block(512, 1, 1);
+  hipLaunchKernelGGL((ttm_kernel<MT, T>), grid, block, lds_bytes, st, a);
+  return hipGetLastError();
+}
+
+int ttm_max_mt(int dtype) { return dtype == CALS_F32 ? 20 : 10; }
+
+hipError_t ttm_launch(const TtmArgs &a, hipStream_t st) {
+  if (a.MT < 1 || a.MT > ttm_max_mt(a.dtype)) return hipErrorInvalidValue;
+  if (a.dtype == CALS_F32) {
+    switch (a.MT) {
+#define CASE(N) case N: return ttm_launch_mt<N, float>(a, st);
+      CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9) CASE(10) CASE(11)
+      CASE(12) CASE(13) CASE(14) CASE(15) CASE(16) CASE(17) CASE(18) CASE(19) CASE(20)
+#undef CASE
+    }
+    return hipErrorInvalidValue;
+  }
+  switch (a.MT) {
+#define CASE(N) case N: return ttm_launch_mt<N, double>(a, st);
+    CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9) CASE(10)
+#undef CASE
+  }
+  return hipErrorInvalidValue;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Pt[nb][a][128] = P[a, 128 nb + cc] (zero for a >= A or column >= R): the B-operand tiles of the
+// TTM as contiguous 16 x 128 blocks (one 1-KiB LDS-DMA piece per row in fp64)
+// ---------------------------------------------------------------------------------------------
+template <typename E>
+__global__ void __launch_bounds__(256) pack_pt_kernel(const E *P, long long ldP, int A, int Ap,
+                                                      int R, E *Pt) {
+  __shared__ E tile[32][33];
+  const int a0 = blockIdx.x * 32, c0 = blockIdx.y * 32;  // 32 x 32 transpose tiles
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int j = ty; j < 32; j += 8) {
+    const int a = a0 + tx, c = c0 + j;
+    tile[j][tx] = (a < A && c < R) ? P[a + ldP * c] : (E)0;
+  }
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8) {
+    const int a = a0 + j, c = c0 + tx;
+    if (a < Ap) Pt[((long long)(c >> 7) * Ap + a) * CALS_BN + (c & (CALS_BN - 1))] = tile[tx][j];
+  }
+}
+
+hipError_t pack_pt_launch(const void *P, long long ldP, int A, int Ap, int NB, int R, void *Pt,
+                          int dtype, hipStream_t st) {
+  const dim3 grid((Ap + 31) / 32, NB * (CALS_BN / 32)), block(256);
+  if (dtype == CALS_F32)
+    hipLaunchKernelGGL(pack_pt_kernel<float>, grid, block, 0, st, (const float *)P, ldP, A, Ap, R,
+                       (float *)Pt);
+  else
+    hipLaunchKernelGGL(pack_pt_kernel<double>, grid, block, 0, st, (const double *)P, ldP, A, Ap,
+                       R, (double *)Pt);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// G_second[s, c] = sum_m T[c][s][m] * F[m, c]: one workgroup per column, one wave per s, fixed
+// summation tree (lane-strided partial sums in fp64, then a butterfly) => deterministic.
+// ---------------------------------------------------------------------------------------------
+template <typename E>
+__global__ void __launch_bounds__(256) contract_kernel(const E *Tb, long long S, int Mp, int M,
+                                                       const E *F, long long ldF, E *out,
+                                                       long long ldOut) {
+  const int c = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  constexpr int NI = 8;  // register-cached rows of F[:, c] per lane: M <= 512 without re-reads
+  double f[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int m = lane + 64 * i;
+    f[i] = (m < M) ? (double)F[m + ldF * c] : 0.0;
+  }
+  const E *Tc = Tb + (long long)c * S * Mp;
+  for (long long s = blockIdx.y * 4 + wave; s < S; s += 4 * gridDim.y) {
+    const E *row = Tc + s * Mp;
+    double acc = 0.0;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int m = lane + 64 * i;
+      if (m < M) acc += (double)row[m] * f[i];
+    }
+    for (int m = lane + 64 * NI; m < M; m += 64) acc += (double)row[m] * (double)F[m + ldF * c];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if (lane == 0) out[s + ldOut * c] = (E)acc;
+  }
+}
+
+hipError_t contract_launch(const void *Tb, long long S, int Mp, int M, const void *F,
+                           long long ldF, void *out, long long ldOut, int R, int dtype,
+                           hipStream_t st) {
+  if (R <= 0) return hipSuccess;
+  int gy = (int)((S + 63) / 64);  // >= 16 s values per wave
+  if (gy < 1) gy = 1;
+  const dim3 grid(R, gy), block(256);
+  if (dtype == CALS_F32)
+    hipLaunchKernelGGL(contract_kernel<float>, grid, block, 0, st, (const float *)Tb, S, Mp, M,
+                       (const float *)F, ldF, (float *)out, ldOut);
+  else
+    hipLaunchKernelGGL(contract_kernel<double>, grid, block, 0, st, (const double *)Tb, S, Mp, M,
+                       (const double *)F, ldF, (double *)out, ldOut);
+  return hipGetLastError();
+}
+
+}  // namespace calship

@@ -78,6 +78,14 @@ typedef struct {
   double update_ms;
   int64_t other_launches;
   double other_ms;
+  /* dimension-tree pair (3-way tensors): the TTM GEMM that replaces two of the three MTTKRPs of a
+   * sweep (flops counted as one MTTKRP: 2*prod(modes)*R) and the HBM-bound contraction of T */
+  int64_t ttm_launches;
+  double ttm_ms;
+  double ttm_flops;
+  int64_t contract_launches;
+  double contract_ms;
+  double contract_bytes;
 } cals_hip_kernel_stats;
 
 void cals_hip_default_params(cals_hip_params *p);
@@ -99,6 +107,12 @@ int cals_hip_create(cals_hip_engine **out, int n_modes, const int64_t *modes, in
 int cals_hip_create_ex(cals_hip_engine **out, int n_modes, const int64_t *modes,
                        int64_t buffer_size, int device, int dtype);
 int cals_hip_dtype(const cals_hip_engine *e);
+/* MTTKRP plan of a 3-way engine, fixed at create: 0 = three fused MTTKRPs per sweep
+ * (mttkrp::MTTKRP semantics, src/utils/mttkrp.cpp:218-328); 1 = modes 0 and 1 share T = X x_2 C
+ * (dimension tree "A"); 2 = modes 1 and 2 share T = X x_0 A (tree "B") -- the reference's two-step
+ * association (mttkrp.cpp:330-560) with the TTM reused by two modes.  Chosen by a cost model;
+ * CALS_HIP_TREE=0|A|B in the environment at create overrides it. */
+int cals_hip_tree(const cals_hip_engine *e);
 int cals_hip_destroy(cals_hip_engine *e);
 const char *cals_hip_last_error(const cals_hip_engine *e);
 

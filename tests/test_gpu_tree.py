@@ -1,0 +1,151 @@
+"""Dimension-tree MTTKRP plans (ttm_kernel.hip): modes (0,1) share T = X x_2 C ("A") or modes (1,2)
+share T = X x_0 A ("B").  Same oracle, same tolerances as the plain plan (test_gpu_parity.py): the
+plan only re-associates the sums, exactly like the reference's own two-step variants
+(src/utils/mttkrp.cpp:330-560), which the oracle also restates (TWOSTEP0/1)."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import make_models, reconstruct, rel
+from test_gpu_parity import TOL_KERNEL, TOL_RUN, _assert_models_match, _run_both, engine_with
+
+pytestmark = pytest.mark.gpu
+PLANS = {"0": 0, "A": 1, "B": 2}
+
+
+@pytest.fixture(params=["A", "B", "0"])
+def plan(request):
+    old = os.environ.get("CALS_HIP_TREE")
+    os.environ["CALS_HIP_TREE"] = request.param
+    yield request.param
+    if old is None:
+        del os.environ["CALS_HIP_TREE"]
+    else:
+        os.environ["CALS_HIP_TREE"] = old
+
+
+@pytest.mark.parametrize("modes,ranks", [
+    ([20, 20, 20], [2, 3, 4, 5]),            # BASELINE config 1
+    ([7, 5, 3], [1, 2, 3]),                  # tiny, ragged
+    ([13, 12, 11], list(range(1, 13))),
+    ([100, 37, 41], None),
+    ([299, 301, 41], None),                  # BASELINE config 4 shape
+    ([330, 17, 9], [5, 20, 7]),              # 21 m-tiles: three M blocks of 7 (fp64)
+    ([17, 330, 9], [5, 20, 7]),
+    ([40, 30, 20], [20] * 21),               # R = 420: four column blocks
+    ([161, 23, 50], [32, 1, 20]),            # 11 m-tiles: M blocks of 6 and 5 tiles (k_big = 1)
+])
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_tree_mttkrp_every_mode_vs_oracle(cc, oracle, inputs, plan, modes, ranks, dtype):
+    if ranks is None:
+        ranks = inputs.ranks_1_to_20(20)
+    X = inputs.tensor(modes, 0)
+    base = make_models(inputs, modes, ranks)
+    e = cc.Engine(modes, sum(ranks), dtype=dtype)
+    assert e.tree == PLANS[plan]
+    e.set_tensor(X)
+    for fs, lam, _ in base:
+        e.enqueue(cc.Model([f.copy() for f in fs], lam.copy()))
+    e.admit()
+    facs = [np.asfortranarray(np.hstack([fs[n] for fs, _, _ in base])) for n in range(3)]
+    tol = TOL_KERNEL if dtype == "f64" else 2e-5
+    for n in range(3):
+        assert rel(e.debug_mttkrp(n), oracle.mttkrp(X, modes, facs, n, oracle.MTTKRP)) < tol
+    e.close()
+
+
+def test_auto_plan_prefers_a_tree_for_the_baseline_shapes(cc):
+    old = os.environ.pop("CALS_HIP_TREE", None)
+    try:
+        e = cc.Engine([300, 300, 300], 2656)
+        assert e.tree in (1, 2)
+        e.close()
+        e = cc.Engine([299, 301, 41], 5328, dtype="f32")
+        assert e.tree == 2        # contract over the 299-mode; T is J*K*R = 263 MB
+        e.close()
+        e = cc.Engine([6, 5, 4, 3], 12)
+        assert e.tree == 0        # 3-way only
+        e.close()
+    finally:
+        if old is not None:
+            os.environ["CALS_HIP_TREE"] = old
+
+
+@pytest.mark.parametrize("modes,ranks,iters", [
+    ([20, 20, 20], [2, 3, 4, 5], 50),
+    ([13, 12, 11], list(range(1, 13)) * 3, 30),
+    ([50, 40, 30], None, 10),
+])
+def test_tree_forced_iterations_vs_oracle(cc, oracle, inputs, plan, modes, ranks, iters):
+    if ranks is None:
+        ranks = inputs.ranks_1_to_20(40)
+    X = inputs.tensor(modes, 3)
+    gm, om, rep, ro = _run_both(cc, oracle, inputs, modes, ranks, X, iters)
+    assert rep.iter == ro.iter == iters
+    _assert_models_match(gm, om, ro.X_norm ** 2)
+
+
+def test_tree_line_search_vs_oracle(cc, oracle, inputs, plan):
+    modes, ranks = [20, 20, 20], [2, 3, 4, 5, 20, 17]
+    X = inputs.tensor(modes, 3)
+    gm, om, rep, ro = _run_both(cc, oracle, inputs, modes, ranks, X, 25, line_search=1,
+                                line_search_interval=5)
+    assert (rep.ls_performed, rep.ls_failed) == (ro.ls_performed, ro.ls_failed)
+    assert rep.ls_performed > 0
+    _assert_models_match(gm, om, ro.X_norm ** 2)
+
+
+def test_tree_jackknife_models_vs_oracle(cc, oracle, inputs, plan):
+    modes, comp = [20, 9, 12], 5
+    X = inputs.low_rank_tensor(modes, comp, seed=21)[0]
+    jk = [(0, i) for i in range(20)]
+    gm, om, rep, ro = _run_both(cc, oracle, inputs, modes, [comp] * 20, X, 20, jk=jk)
+    _assert_models_match(gm, om, ro.X_norm ** 2)
+    for i, m in enumerate(gm):
+        assert np.all(m.factors[0][i, :] == 0.0)
+
+
+def test_tree_queue_eviction_compress_vs_oracle(cc, oracle, inputs, plan):
+    """60 models through a 30-column buffer with tolerance-driven eviction: the active width R
+    changes from sweep to sweep, so T, Pt and the team split are re-derived every sweep."""
+    modes = [13, 12, 11]
+    ranks = [1 + (k % 10) for k in range(60)]
+    X = inputs.low_rank_tensor(modes, 4, seed=5)[0] + 0.1 * inputs.tensor(modes, 7)
+    gm, om, rep, ro = _run_both(cc, oracle, inputs, modes, ranks, X, 40, buffer=30,
+                                force_max_iter=0, tol=1e-6)
+    assert (rep.iter, rep.n_ktensors, rep.ktensor_comp_sum) == (ro.iter, ro.n_ktensors, ro.ktensor_comp_sum)
+    for a, b in zip(gm, om):
+        assert a.iters == b.iters
+        # reference criterion: reconstructed tensors agree (MODEL_DIFF_ACC, test_cals.cpp:7,81-84)
+        d = np.linalg.norm(reconstruct(a.factors, a.lam, modes) - reconstruct(b.factors, b.lam, modes))
+        assert d <= 1e-9
+
+
+def test_full_size_c3_tree_identities(cc, inputs, plan):
+    """300^3, 256 models (R = 2656): all-ones model => mode sums of X; random columns vs einsum."""
+    if plan == "0":
+        pytest.skip("plain plan at full size: test_gpu_parity.py")
+    modes = [300, 300, 300]
+    X = inputs.tensor(modes, 0)
+    ranks = inputs.ranks_1_to_20(256)
+    base = make_models(inputs, modes, ranks)
+    for n in range(3):
+        base[0][0][n][:] = 1.0
+    e = cc.Engine(modes, sum(ranks))
+    e.set_tensor(X)
+    for fs, lam, _ in base:
+        e.enqueue(cc.Model(fs, lam))
+    e.admit()
+    X3 = X.reshape(modes, order="F")
+    G = [e.debug_mttkrp(n) for n in range(3)]
+    assert rel(G[0][:, 0], X3.sum(axis=(1, 2))) < 1e-12
+    assert rel(G[1][:, 0], X3.sum(axis=(0, 2))) < 1e-12
+    assert rel(G[2][:, 0], X3.sum(axis=(0, 1))) < 1e-12
+    rng = np.random.default_rng(0)
+    facs = [np.hstack([fs[n] for fs, _, _ in base]) for n in range(3)]
+    for c in rng.integers(1, sum(ranks), size=3):
+        assert rel(G[0][:, c], np.einsum("ijk,j,k->i", X3, facs[1][:, c], facs[2][:, c])) < 1e-11
+        assert rel(G[1][:, c], np.einsum("ijk,i,k->j", X3, facs[0][:, c], facs[2][:, c])) < 1e-11
+        assert rel(G[2][:, c], np.einsum("ijk,i,j->k", X3, facs[0][:, c], facs[1][:, c])) < 1e-11
+    e.close()
