@@ -421,10 +421,18 @@ int launch_ttm(cals_hip_engine *e, int64_t R, Geo *geo_out) {
   a.NB = g.NB;
   a.T = g.T;
   a.ldPart = L.ldPart;
-  a.grid = g.NB * g.T;
+  a.grid = g.NB * g.T * tp.m_blocks;
+  {
+    // P panels of one locality group: <= 2 MB of an XCD's 4 MB L2 (CALS_TTM_NBW overrides)
+    const size_t panel = (size_t)L.Ap * CALS_BN * e->es;
+    long long nbw = (long long)((2u << 20) / std::max<size_t>(panel, 1));
+    if (const char *v = getenv("CALS_TTM_NBW")) nbw = atoi(v);
+    a.nbw = (int)std::min<long long>(std::max<long long>(nbw, 1), g.NB);
+  }
   a.m_blocks = tp.m_blocks;
   a.k_big = tp.k_big;
   a.MT = tp.MT;
+  a.dbg = getenv("CALS_TTM_DBG") ? atoi(getenv("CALS_TTM_DBG")) : 0;
   if ((size_t)g.NB * g.T * (size_t)L.ldPart * CALS_BN > e->partial_elems)
     return fail(e, CALS_HIP_ERR_STATE, "internal: partial buffer too small");
   double total = 1.0;

@@ -64,8 +64,10 @@ struct TtmArgs {
   int Mp, Ap, R;
   int NB, T;         // column blocks, team size (workgroups per column block and M block; split s)
   int ldPart;
-  int grid;          // NB * T
+  int grid;          // NB * T * m_blocks workgroups (1-D)
+  int nbw;           // column blocks per XCD-locality group (ttm_kernel's workgroup mapping)
   int m_blocks, k_big, MT;  // M blocks: the first k_big are MT tiles high, the others MT - 1
+  int dbg;           // timing experiments (CALS_TTM_DBG): 1 = skip the T stores, 2 = no stagger
 };
 int ttm_max_mt(int dtype);
 hipError_t ttm_launch(const TtmArgs &a, hipStream_t st);

@@ -46,7 +46,9 @@ struct TtmCfg {
   static constexpr int PPR = CALS_BN / PPE;          // instructions per P row: 1 | 2
   static constexpr int NPP = 16 * PPR / 8;           // P instructions per wave: 2 | 4
   static constexpr int BUF = POFF + 16 * PP;
-  static constexpr int LDS_BYTES = 3 * BUF * ES;
+  static constexpr int SP = 144 / ES;                // staging tile pitch: 18 f64 | 36 f32 per column
+  static constexpr int STG = 16 * SP;                // per-wave staging tile (T flush transpose)
+  static constexpr int LDS_BYTES = (3 * BUF + 8 * STG) * ES;
   static constexpr int N = 4 * MT;                   // MFMAs per slab per wave
   static constexpr int RING = (ES == 4) ? 8 : 6;
   static constexpr int D = N < RING ? N : RING;      // operand ring depth
@@ -84,7 +86,8 @@ struct TtmPipe {
 
 template <int MT, typename T>
 struct TtmBody {
-static __device__ __forceinline__ void run(const TtmArgs &a, const int m0, unsigned char *lds_raw) {
+static __device__ __forceinline__ void run(const TtmArgs &a, const int m0, const int tm, const int nb,
+                                           unsigned char *lds_raw) {
   typedef TtmCfg<MT, T> C;
   typedef TtmPipe<MT, T> P3;
   typedef typename Acc<T>::type acc_t;
@@ -98,14 +101,6 @@ static __device__ __forceinline__ void run(const TtmArgs &a, const int m0, unsig
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int krow = lane >> 4;
   const int lcol = lane & 15;
-
-  // XCD-aware bijective remap (as mttkrp3_kernel): consecutive p share an XCD
-  const int G = a.grid;
-  const int b = blockIdx.x;
-  const int xcd = b & 7, q8 = G >> 3, r8 = G & 7;
-  const int p = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (b >> 3);
-  const int tm = p / a.NB;
-  const int nb = p - tm * a.NB;
 
   const long long S = a.S;
   const int nAb = a.Ap >> 4;
@@ -209,25 +204,75 @@ static __device__ __forceinline__ void run(const TtmArgs &a, const int m0, unsig
   const unsigned lds0 = (unsigned)(size_t)((LDS_AS const char *)lds_raw);
   const unsigned q_lane_off = (unsigned)((C::QOFF + wave * 16 + lcol) * C::ES);
   const unsigned p_lane_off = (unsigned)((C::POFF + krow * C::PP + wave * 16 + lcol) * C::ES);
-  T *const Tcol = static_cast<T *>(a.Tout) + ((long long)(cvalid ? col : 0) * S) * a.Mp + m0;
+  // ---- T flush through a per-wave LDS staging tile, so that every global store instruction writes
+  // whole 128-byte lines (8 lanes x 16 B per column).  Stores straight from the MFMA register layout
+  // cover a quarter (fp64) or half (fp32) line per instruction and make the L2 fetch each line
+  // before merging it: measured with rocprofv3 FETCH_SIZE, 2.0 GB of fills per launch at C3.
+  T *const stg = lds + 3 * C::BUF + wave * C::STG;
+  const int j8 = lane & 7;
+  T *tb[2];
+  bool tv[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int c8 = (lane >> 3) + 8 * h;
+    const int gc = nb * CALS_BN + wave * 16 + c8;
+    tv[h] = gc < a.R;
+    tb[h] = static_cast<T *>(a.Tout) + ((long long)(tv[h] ? gc : 0) * S) * a.Mp + m0 + (16 / C::ES) * j8;
+  }
+  // fp32, odd MT: the last tile alone (16 rows = 64 B per column, 4 lanes per column)
+  const int gc4 = nb * CALS_BN + wave * 16 + (lane >> 2);
+  const bool tv4 = gc4 < a.R;
+  T *const tb4 = static_cast<T *>(a.Tout) + ((long long)(tv4 ? gc4 : 0) * S) * a.Mp + m0 + 4 * (lane & 3);
 
   // end of an s: G += T * Q[s, c]; T -> HBM; T = 0
   auto flush = [&](long long s, T qv) {
-    T *tp = Tcol + s * a.Mp;
+    asm volatile("" ::: "memory");
+    const long long so = s * a.Mp;
+    const bool st = !(a.dbg & 1);
+    if constexpr (C::ES == 8) {
+      typedef double v2d __attribute__((ext_vector_type(2)));
 #pragma unroll
-    for (int t = 0; t < MT; ++t) {
+      for (int t = 0; t < MT; ++t) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) gacc[t][r] += tacc[t][r] * qv;
-      if (cvalid) {
-        if constexpr (C::ES == 4) {
-          *reinterpret_cast<acc_t *>(tp + 16 * t + 4 * krow) = tacc[t];  // rows 4 krow .. +3
-        } else {
+        for (int r = 0; r < 4; ++r) {
+          gacc[t][r] += tacc[t][r] * qv;
+          stg[lcol * C::SP + krow + 4 * r] = tacc[t][r];
+        }
+        tacc[t] = (acc_t){0, 0, 0, 0};
 #pragma unroll
-          for (int r = 0; r < 4; ++r) tp[16 * t + krow + 4 * r] = tacc[t][r];
+        for (int h = 0; h < 2; ++h) {
+          const v2d v = *reinterpret_cast<const v2d *>(stg + ((lane >> 3) + 8 * h) * C::SP + 2 * j8);
+          if (tv[h] && st) __builtin_nontemporal_store(v, reinterpret_cast<v2d *>(tb[h] + so + 16 * t));
         }
       }
-      tacc[t] = (acc_t){0, 0, 0, 0};
+    } else {
+#pragma unroll
+      for (int t = 0; t + 1 < MT; t += 2) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) gacc[t + k][r] += tacc[t + k][r] * qv;
+          *reinterpret_cast<acc_t *>(stg + lcol * C::SP + 16 * k + 4 * krow) = tacc[t + k];
+          tacc[t + k] = (acc_t){0, 0, 0, 0};
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const acc_t v = *reinterpret_cast<const acc_t *>(stg + ((lane >> 3) + 8 * h) * C::SP + 4 * j8);
+          if (tv[h] && st) __builtin_nontemporal_store(v, reinterpret_cast<acc_t *>(tb[h] + so + 16 * t));
+        }
+      }
+      if constexpr (MT % 2 == 1) {
+        constexpr int t = MT - 1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) gacc[t][r] += tacc[t][r] * qv;
+        *reinterpret_cast<acc_t *>(stg + lcol * C::SP + 4 * krow) = tacc[t];
+        tacc[t] = (acc_t){0, 0, 0, 0};
+        const acc_t v = *reinterpret_cast<const acc_t *>(stg + (lane >> 2) * C::SP + 4 * (lane & 3));
+        if (tv4 && st) __builtin_nontemporal_store(v, reinterpret_cast<acc_t *>(tb4 + so + 16 * t));
+      }
     }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
   };
 
   int buf = 0;
@@ -319,7 +364,7 @@ static __device__ __forceinline__ void run(const TtmArgs &a, const int m0, unsig
       if (pend) flush(s_pend, q_pend);
     }
   };
-  if (wave < 4)
+  if (wave < 4 && !(a.dbg & 2))
     unit_loop.template operator()<false>();
   else
     unit_loop.template operator()<true>();
@@ -342,14 +387,31 @@ static __device__ __forceinline__ void run(const TtmArgs &a, const int m0, unsig
 template <int MT, typename T>
 __global__ void __launch_bounds__(512, 2) ttm_kernel(const TtmArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  const int by = blockIdx.y;
+  // Workgroup -> (column block nb, team member tm, M block by).  XCD-aware bijective remap first
+  // (workgroups with equal blockIdx % 8 share an XCD and get consecutive p), then p enumerates
+  // groups of `nbw` column blocks; inside a group all (tm, by) pairs, column block fastest.  One
+  // XCD's ~grid/8 consecutive p therefore touch few distinct P panels (nbw * Ap * 128 elements fit
+  // its 4 MB L2 and are re-read once per s) and few distinct (tm, by), i.e. X slabs, each shared
+  // by the nbw workgroups that stream it at the same time.
+  const int G = a.grid;
+  const int b = blockIdx.x;
+  const int xcd = b & 7, q8 = G >> 3, r8 = G & 7;
+  const int p = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (b >> 3);
+  const int TY = a.T * a.m_blocks;
+  const int g = p / (a.nbw * TY);
+  const int wg = min(a.nbw, a.NB - g * a.nbw);
+  const int rem = p - g * a.nbw * TY;
+  const int ty = rem / wg;
+  const int nb = g * a.nbw + (rem - ty * wg);
+  const int tm = ty / a.m_blocks;
+  const int by = ty - tm * a.m_blocks;
   if constexpr (MT > 1) {
     if (by >= a.k_big) {
-      TtmBody<MT - 1, T>::run(a, 16 * (a.k_big * MT + (by - a.k_big) * (MT - 1)), lds_raw);
+      TtmBody<MT - 1, T>::run(a, 16 * (a.k_big * MT + (by - a.k_big) * (MT - 1)), tm, nb, lds_raw);
       return;
     }
   }
-  TtmBody<MT, T>::run(a, 16 * by * MT, lds_raw);
+  TtmBody<MT, T>::run(a, 16 * by * MT, tm, nb, lds_raw);
 }
 
 template <int MT, typename T>
@@ -362,7 +424,7 @@ static hipError_t ttm_launch_mt(const TtmArgs &a, hipStream_t st) {
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  dim3 grid(a.grid, a.m_blocks, 1), block(512, 1, 1);
+  dim3 grid(a.grid, 1, 1), block(512, 1, 1);
   hipLaunchKernelGGL((ttm_kernel<MT, T>), grid, block, lds_bytes, st, a);
   return hipGetLastError();
 }
