@@ -192,7 +192,9 @@ def main():
                          "flops_per_launch": flops_per_launch, "avg_launch_ms": round(avg_ms, 4),
                          "launches": kern[dom]["launches"],
                          "plan": {0: "3 fused MTTKRPs per sweep", 1: "dimension tree A (modes 0,1 share X x_2 C)",
-                                  2: "dimension tree B (modes 1,2 share X x_0 A)"}[plan],
+                                  2: "dimension tree B (modes 1,2 share X x_0 A)",
+                                  3: "multi-sweep dimension tree (every TTM shared by two consecutive "
+                                     "updates: 3 TTMs per 2 sweeps)"}[plan],
                          "mfma_kernels": kern, "contract_kernel": contract,
                          "other_kernels_ms_per_step": round((ks.update_ms + ks.other_ms) / args.steps, 4)},
         }

@@ -63,7 +63,7 @@ EXPORTS = [
     "cals_hip_set_tensor", "cals_hip_set_params", "cals_hip_enqueue", "cals_hip_run",
     "cals_hip_model_result", "cals_hip_admit", "cals_hip_sweep", "cals_hip_evict",
     "cals_hip_active_cols", "cals_hip_models_in_flight", "cals_hip_queue_size",
-    "cals_hip_synchronize", "cals_hip_debug_mttkrp", "cals_hip_debug_get_factor",
+    "cals_hip_synchronize", "cals_hip_debug_mttkrp", "cals_hip_debug_mttkrp_path", "cals_hip_debug_get_factor",
     "cals_hip_debug_get_lambda", "cals_hip_debug_get_gramian", "cals_hip_debug_model_status",
     "cals_hip_debug_get_norms", "cals_hip_set_profiling", "cals_hip_get_kernel_stats",
     "cals_hip_reset_kernel_stats", "cals_hip_stream", "cals_hip_device_count",
@@ -105,6 +105,7 @@ def load_library():
         getattr(lib, f).restype = i64
     lib.cals_hip_synchronize.argtypes = [vp]
     lib.cals_hip_debug_mttkrp.argtypes = [vp, C.c_int, dp]
+    lib.cals_hip_debug_mttkrp_path.argtypes = [vp, C.c_int, C.c_int, dp]
     lib.cals_hip_debug_get_factor.argtypes = [vp, C.c_int, dp]
     lib.cals_hip_debug_get_lambda.argtypes = [vp, dp]
     lib.cals_hip_debug_get_gramian.argtypes = [vp, C.c_int, dp]
@@ -283,10 +284,16 @@ class Engine:
     def queue_size(self):
         return int(self.lib.cals_hip_queue_size(self.h))
 
-    def debug_mttkrp(self, mode):
+    def debug_mttkrp(self, mode, path=None):
+        """path: None = the path a sweep takes under the engine's plan; "plain" | "first" | "second"
+        = cals_hip_debug_mttkrp_path (raises CalsHipError if the plan has no such path)."""
         R = self.active_cols
         G = np.zeros((self.modes[mode], R), order="F")
-        self._chk(self.lib.cals_hip_debug_mttkrp(self.h, int(mode), _dp(G)))
+        if path is None:
+            self._chk(self.lib.cals_hip_debug_mttkrp(self.h, int(mode), _dp(G)))
+        else:
+            code = {"plain": 0, "first": 1, "second": 2}[path]
+            self._chk(self.lib.cals_hip_debug_mttkrp_path(self.h, int(mode), code, _dp(G)))
         return G
 
     def debug_factor(self, mode):

@@ -46,14 +46,25 @@ struct ModeLayout {
   int MT2 = 0, m_blocks2 = 1, k_big2 = 0;      // v2 tiling (two 4-wave workgroups per CU)
 };
 
-// Dimension-tree pair for 3-way tensors (ttm_kernel.hip): modes `first` and `second` (consecutive
-// in the sweep) share T = X x_a P; the remaining mode runs the plain fused MTTKRP.
-struct TreePlan {
+// Dimension-tree plans for 3-way tensors (ttm_kernel.hip).  pair[n]: modes n ("first") and
+// (n+1)%3 ("second"), consecutive in the update order A B C A B C ..., share T = X x_a P with
+// a = (n+2)%3, the mode that neither of them updates.  kind 1 ("A") enables pair 0, kind 2 ("B")
+// pair 1 (the third mode runs the plain fused MTTKRP); kind 3 ("M", multi-sweep dimension tree)
+// enables all three, so every TTM serves two consecutive updates also across the sweep boundary:
+// 3 TTMs per 2 sweeps instead of 2 per sweep.
+struct PairCfg {
   bool on = false;
-  int first = 0, second = 1, a = 2;
   int MT = 0, m_blocks = 1, k_big = 1;
-  void *Tbuf = nullptr;  // T[c][s][m]: buffer x S x Mp elements
+};
+struct TreePlan {
+  int kind = 0;
+  bool on = false;
+  PairCfg pair[3];
+  void *Tbuf = nullptr;  // T[c][s][m]: buffer x max(S x Mp) elements
   void *Pt = nullptr;    // packed factor of mode a: [NB][Ap][CALS_BN]
+  int t_second = -1;     // T currently holds the TTM whose `second` is this mode (-1: none) ...
+  int t_first = -1;      // ... computed as pair[t_first]
+  int *d_changed = nullptr;  // set by ls_kernel when a line-search step rewrote factors
 };
 
 struct EventPair {
@@ -384,33 +395,36 @@ int launch_mttkrp(cals_hip_engine *e, int mode, int64_t R, Geo *geo_out) {
   return CALS_HIP_OK;
 }
 
-// TTM of the tree pair: T = X x_a P (to HBM) and the partial tiles of G_first
-Geo tree_geometry(const cals_hip_engine *e, int64_t R) {
-  const TreePlan &tp = e->tree;
+// TTM of pair[first]: T = X x_a P (to HBM) and the partial tiles of G_first
+Geo tree_geometry(const cals_hip_engine *e, int first, int64_t R) {
+  const PairCfg &pc = e->tree.pair[first];
+  const int second = (first + 1) % 3;
   Geo g;
   g.NB = (int)((R + CALS_BN - 1) / CALS_BN);
-  long long T = e->n_cu / std::max(1, g.NB * tp.m_blocks);
+  long long T = e->n_cu / std::max(1, g.NB * pc.m_blocks);
   if (T < 1) T = 1;
-  if (T > e->modes[tp.second]) T = e->modes[tp.second];
+  if (T > e->modes[second]) T = e->modes[second];
   g.T = (int)T;
   return g;
 }
 
-int launch_ttm(cals_hip_engine *e, int64_t R, Geo *geo_out) {
-  const TreePlan &tp = e->tree;
-  const ModeLayout &L = e->lay[tp.first];
-  const Geo g = tree_geometry(e, R);
+int launch_ttm(cals_hip_engine *e, int first, int64_t R, Geo *geo_out) {
+  TreePlan &tp = e->tree;
+  const PairCfg &pc = tp.pair[first];
+  const int second = (first + 1) % 3, am = (first + 2) % 3;
+  const ModeLayout &L = e->lay[first];
+  const Geo g = tree_geometry(e, first, R);
   {
     const int pk = prof_begin(e, 2, 0);
-    HIPCHK(pack_pt_launch(e->factor[tp.a], e->modes[tp.a], L.A, L.Ap, g.NB, (int)R, tp.Pt, e->dtype,
+    HIPCHK(pack_pt_launch(e->factor[am], e->modes[am], L.A, L.Ap, g.NB, (int)R, tp.Pt, e->dtype,
                           e->stream));
     prof_end(e, pk);
   }
   TtmArgs a{};
   a.Xp = L.Xp;
   a.Pt = tp.Pt;
-  a.Q = e->factor[tp.second];
-  a.ldQ = e->modes[tp.second];
+  a.Q = e->factor[second];
+  a.ldQ = e->modes[second];
   a.partial = e->partial;
   a.Tout = tp.Tbuf;
   a.dtype = e->dtype;
@@ -421,7 +435,7 @@ int launch_ttm(cals_hip_engine *e, int64_t R, Geo *geo_out) {
   a.NB = g.NB;
   a.T = g.T;
   a.ldPart = L.ldPart;
-  a.grid = g.NB * g.T * tp.m_blocks;
+  a.grid = g.NB * g.T * pc.m_blocks;
   {
     // P panels of one locality group: <= 2 MB of an XCD's 4 MB L2 (CALS_TTM_NBW overrides)
     const size_t panel = (size_t)L.Ap * CALS_BN * e->es;
@@ -429,9 +443,9 @@ int launch_ttm(cals_hip_engine *e, int64_t R, Geo *geo_out) {
     if (const char *v = getenv("CALS_TTM_NBW")) nbw = atoi(v);
     a.nbw = (int)std::min<long long>(std::max<long long>(nbw, 1), g.NB);
   }
-  a.m_blocks = tp.m_blocks;
-  a.k_big = tp.k_big;
-  a.MT = tp.MT;
+  a.m_blocks = pc.m_blocks;
+  a.k_big = pc.k_big;
+  a.MT = pc.MT;
   a.dbg = getenv("CALS_TTM_DBG") ? atoi(getenv("CALS_TTM_DBG")) : 0;
   if ((size_t)g.NB * g.T * (size_t)L.ldPart * CALS_BN > e->partial_elems)
     return fail(e, CALS_HIP_ERR_STATE, "internal: partial buffer too small");
@@ -440,21 +454,27 @@ int launch_ttm(cals_hip_engine *e, int64_t R, Geo *geo_out) {
   const int pk = prof_begin(e, 3, 2.0 * total * (double)R);
   HIPCHK(ttm_launch(a, e->stream));
   prof_end(e, pk);
+  tp.t_first = first;
+  tp.t_second = second;
   if (geo_out) *geo_out = g;
   return CALS_HIP_OK;
 }
 
-// G_second[s, c] = sum_m T[m, s, c] F_first[m, c], written to `out` (ld = I_second)
+// G_second[s, c] = sum_m T[m, s, c] F_first[m, c] for the T in the buffer, written to `out`
+// (ld = I_second)
 int launch_contract(cals_hip_engine *e, int64_t R, void *out) {
   const TreePlan &tp = e->tree;
-  const ModeLayout &L = e->lay[tp.first];
+  const int first = tp.t_first, second = tp.t_second;
+  const ModeLayout &L = e->lay[first];
   const double bytes = (double)R * (double)L.S * (double)L.Mp * (double)e->es;
   const int pk = prof_begin(e, 4, bytes);
-  HIPCHK(contract_launch(tp.Tbuf, L.S, L.Mp, (int)e->modes[tp.first], e->factor[tp.first],
-                         e->modes[tp.first], out, e->modes[tp.second], (int)R, e->dtype, e->stream));
+  HIPCHK(contract_launch(tp.Tbuf, L.S, L.Mp, (int)e->modes[first], e->factor[first],
+                         e->modes[first], out, e->modes[second], (int)R, e->dtype, e->stream));
   prof_end(e, pk);
   return CALS_HIP_OK;
 }
+
+void tree_invalidate(cals_hip_engine *e) { e->tree.t_second = e->tree.t_first = -1; }
 
 LsArgs make_ls_args(cals_hip_engine *e) {
   LsArgs a{};
@@ -495,11 +515,12 @@ int sweep_once(cals_hip_engine *e, bool evict_enabled) {
   }
   for (int n = 0; n < e->n_modes; n++) {
     Geo g{0, 0};
-    const bool by_contract = e->tree.on && n == e->tree.second;
+    const bool by_contract = e->tree.on && e->tree.t_second == n;
     if (by_contract) {
       if ((rc = launch_contract(e, R, e->factor[n]))) return rc;
-    } else if (e->tree.on && n == e->tree.first) {
-      if ((rc = launch_ttm(e, R, &g))) return rc;
+      tree_invalidate(e);  // T is consumed: mode a of the pair is updated next
+    } else if (e->tree.on && e->tree.pair[n].on) {
+      if ((rc = launch_ttm(e, n, R, &g))) return rc;
     } else if ((rc = launch_mttkrp(e, n, R, &g))) {
       return rc;
     }
@@ -531,8 +552,20 @@ int sweep_once(cals_hip_engine *e, bool evict_enabled) {
   if (e->prm.line_search) {
     LsArgs la = make_ls_args(e);
     const int pk = prof_begin(e, 2, 0);
+    const bool pending = e->tree.t_second >= 0;  // a T shared across the sweep boundary
+    if (pending) HIPCHK(hipMemsetAsync(e->tree.d_changed, 0, sizeof(int), e->stream));
+    la.changed = pending ? e->tree.d_changed : nullptr;
     HIPCHK(ls_launch(la, e->stream));
     prof_end(e, pk);
+    if (pending) {
+      // an extrapolation or a revert rewrote some model's factors: T (contracted with one of them)
+      // is stale.  One 4-byte read-back per sweep, only while a T is pending and LS is on.
+      int changed = 0;
+      HIPCHK(hipMemcpyAsync(&changed, e->tree.d_changed, sizeof(int), hipMemcpyDeviceToHost,
+                            e->stream));
+      HIPCHK(hipStreamSynchronize(e->stream));
+      if (changed) tree_invalidate(e);
+    }
   }
   if (!e->prm.always_evict_first || !evict_enabled) {
     FinishArgs f{};
@@ -622,6 +655,7 @@ int remove_models(cals_hip_engine *e, std::vector<int64_t> rm) {
     e->registry.erase(std::find(e->registry.begin(), e->registry.end(), ticket));
   }
   e->slots_dirty = true;
+  tree_invalidate(e);
   adjust_edges(e);
   return CALS_HIP_OK;
 }
@@ -634,6 +668,7 @@ int compress(cals_hip_engine *e) {
     adjust_edges(e);
     return CALS_HIP_OK;
   }
+  tree_invalidate(e);
   for (auto &rq : req) {
     HostModel *m = nullptr;
     for (auto t : e->registry)
@@ -693,6 +728,7 @@ int admit(cals_hip_engine *e, int64_t *n_admitted) {
   }
   if (!admitted.empty()) {
     e->slots_dirty = true;
+    tree_invalidate(e);
     // Ktensor::attach: copy the models' factors into the buffer columns.  Models admitted back to
     // back sit in adjacent columns, so each run goes up as ONE H2D per mode from a staging buffer.
     size_t k0 = 0;
@@ -853,7 +889,7 @@ int cals_hip_create_ex(cals_hip_engine **out, int n_modes, const int64_t *modes,
     }
     return a_mode;
   };
-  // ---- dimension tree (3-way only): CALS_HIP_TREE = 0 | A | B, default: cost model ----
+  // ---- dimension tree (3-way only): CALS_HIP_TREE = 0 | A | B | M, default: cost model ----
   if (n_modes == 3) {
     const double peak = (e->dtype == CALS_F32) ? 157.3e12 * 0.8 : 78.6e12 * 0.9;
     auto eff = [](int mt) { return (double)mt / ((double)mt + 1.0); };  // fitted to measured MT sweeps
@@ -865,34 +901,47 @@ int cals_hip_create_ex(cals_hip_engine **out, int n_modes, const int64_t *modes,
       const double S = (double)modes[3 - n - a_mode];
       return 2.0 * 16.0 * mb * mt * round_up((int)modes[a_mode], 16) * S / (peak * eff(mt));
     };
-    auto tree_cost = [&](int first, int second, int a_mode) {
+    auto pair_cost = [&](int first) {  // TTM (first) + contraction (second), both MTTKRPs
+      const int second = (first + 1) % 3, a_mode = (first + 2) % 3;
       const int Mp = round_up((int)modes[first], 16), tiles = Mp / 16;
       const int mb = (tiles + ttm_max_mt(e->dtype) - 1) / ttm_max_mt(e->dtype);
       const int mt = (tiles + mb - 1) / mb;
       const double S = (double)modes[second];
-      const double ttm = 2.0 * Mp * round_up((int)modes[a_mode], 16) * S / (peak * eff(mt) * 0.97);
-      const double t_bytes = (double)Mp * S * (double)e->es;
-      return ttm + 1.3 * t_bytes / 3.5e12 + plain_cost(a_mode);
+      const double ttm = 2.0 * Mp * round_up((int)modes[a_mode], 16) * S / (peak * eff(mt) * 0.95);
+      return ttm + (double)Mp * S * (double)e->es / 3.5e12;
+    };
+    auto t_bytes = [&](int first) {
+      return (size_t)buffer_size * (size_t)modes[(first + 1) % 3] *
+             (size_t)round_up((int)modes[first], 16) * e->es;
     };
     const double c_plain = plain_cost(0) + plain_cost(1) + plain_cost(2);
-    const double c_a = tree_cost(0, 1, 2), c_b = tree_cost(1, 2, 0);
-    int choice = 0;  // 0 off, 1 = A (modes 0,1 share X x_2 C), 2 = B (modes 1,2 share X x_0 A)
-    if (std::min(c_a, c_b) < 0.97 * c_plain) choice = (c_a <= c_b) ? 1 : 2;
+    const double cost[4] = {c_plain, pair_cost(0) + plain_cost(2), pair_cost(1) + plain_cost(0),
+                            // multi-sweep: 3 pairs per 2 sweeps, + 10 % for T's lost to line search
+                            0.55 * (pair_cost(0) + pair_cost(1) + pair_cost(2))};
+    int choice = 0;
+    for (int k = 1; k < 4; k++)
+      if (cost[k] < 0.97 * c_plain && cost[k] < cost[choice]) choice = k;
     if (const char *v = getenv("CALS_HIP_TREE")) {
       if (v[0] == '0') choice = 0;
       else if (v[0] == 'A' || v[0] == 'a' || v[0] == '1') choice = 1;
       else if (v[0] == 'B' || v[0] == 'b' || v[0] == '2') choice = 2;
+      else if (v[0] == 'M' || v[0] == 'm' || v[0] == '3') choice = 3;
     }
     if (choice) {
       TreePlan &tp = e->tree;
-      tp.first = (choice == 1) ? 0 : 1;
-      tp.second = tp.first + 1;
-      tp.a = (choice == 1) ? 2 : 0;
-      const size_t t_bytes = (size_t)buffer_size * (size_t)modes[tp.second] *
-                             (size_t)round_up((int)modes[tp.first], 16) * e->es;
+      size_t need = 0;
+      for (int n = 0; n < 3; n++) {
+        tp.pair[n].on = (choice == 3) || (choice == 1 && n == 0) || (choice == 2 && n == 1);
+        if (tp.pair[n].on) need = std::max(need, t_bytes(n));
+      }
       size_t free_b = 0, total_b = 0;
       HIPCHK(hipMemGetInfo(&free_b, &total_b));
-      tp.on = t_bytes < free_b / 3;  // T must leave room for X copies and the model state
+      tp.on = need < free_b / 3;  // T must leave room for the X copies and the model state
+      if (tp.on) {
+        tp.kind = choice;
+      } else {
+        for (int n = 0; n < 3; n++) tp.pair[n].on = false;
+      }
     }
   }
 
@@ -900,7 +949,7 @@ int cals_hip_create_ex(cals_hip_engine **out, int n_modes, const int64_t *modes,
   size_t part_rows_max = 0, krp_max = 0;
   for (int n = 0; n < n_modes; n++) {
     ModeLayout &L = e->lay[n];
-    L.a_mode = (e->tree.on && n == e->tree.first) ? e->tree.a : pick_a(n);
+    L.a_mode = (e->tree.on && e->tree.pair[n].on) ? (n + 2) % 3 : pick_a(n);
     L.A = (int)modes[L.a_mode];
     L.Ap = round_up(L.A, 16);
     L.Mp = round_up((int)modes[n], 16);
@@ -930,15 +979,23 @@ int cals_hip_create_ex(cals_hip_engine **out, int n_modes, const int64_t *modes,
   }
   if ((rc = dev_alloc(e, &e->lambda, (size_t)buffer_size))) return rc;
   const size_t nb_max = (size_t)((buffer_size + CALS_BN - 1) / CALS_BN);
+  if ((rc = dev_alloc(e, &e->tree.d_changed, (size_t)1))) return rc;
   if (e->tree.on) {
     TreePlan &tp = e->tree;
-    const ModeLayout &L = e->lay[tp.first];
-    const int tiles = L.Mp / 16, max_mt = ttm_max_mt(e->dtype);
-    tp.m_blocks = (tiles + max_mt - 1) / max_mt;
-    tp.MT = (tiles + tp.m_blocks - 1) / tp.m_blocks;
-    tp.k_big = tiles - tp.m_blocks * (tp.MT - 1);
-    if ((rc = dev_alloc_elems(e, &tp.Pt, nb_max * (size_t)L.Ap * CALS_BN))) return rc;
-    HIPCHK(hipMalloc(&tp.Tbuf, (size_t)buffer_size * (size_t)L.S * (size_t)L.Mp * e->es));
+    size_t t_elems = 0, pt_elems = 0;
+    for (int n = 0; n < 3; n++) {
+      PairCfg &pc = tp.pair[n];
+      if (!pc.on) continue;
+      const ModeLayout &L = e->lay[n];
+      const int tiles = L.Mp / 16, max_mt = ttm_max_mt(e->dtype);
+      pc.m_blocks = (tiles + max_mt - 1) / max_mt;
+      pc.MT = (tiles + pc.m_blocks - 1) / pc.m_blocks;
+      pc.k_big = tiles - pc.m_blocks * (pc.MT - 1);
+      t_elems = std::max(t_elems, (size_t)buffer_size * (size_t)L.S * (size_t)L.Mp);
+      pt_elems = std::max(pt_elems, nb_max * (size_t)L.Ap * CALS_BN);
+    }
+    if ((rc = dev_alloc_elems(e, &tp.Pt, pt_elems))) return rc;
+    HIPCHK(hipMalloc(&tp.Tbuf, t_elems * e->es));
   }
   size_t ld_max = 0;
   for (int n = 0; n < n_modes; n++) ld_max = std::max<size_t>(ld_max, (size_t)e->lay[n].ldPart);
@@ -1008,6 +1065,7 @@ int cals_hip_destroy(cals_hip_engine *e) {
   fr(e->partial);
   fr(e->tree.Tbuf);
   fr(e->tree.Pt);
+  fr(e->tree.d_changed);
   fr(e->krp_ws);
   fr(e->d_jk_norms);
   fr(e->mt.col);
@@ -1097,8 +1155,7 @@ int cals_hip_set_tensor_f32(cals_hip_engine *e, const float *X_host) {
 }
 
 int cals_hip_tree(const cals_hip_engine *e) {
-  if (!e || !e->tree.on) return 0;
-  return e->tree.first == 0 ? 1 : 2;
+  return (e && e->tree.on) ? e->tree.kind : 0;
 }
 
 int cals_hip_dtype(const cals_hip_engine *e) {
@@ -1223,19 +1280,38 @@ int cals_hip_synchronize(cals_hip_engine *e) {
 }
 
 int cals_hip_debug_mttkrp(cals_hip_engine *e, int mode, double *G_host) {
+  // the path a sweep would take for this mode under the engine's plan: as `second` of a pair
+  // if there is one, else as `first`, else the plain fused MTTKRP
+  int path = CALS_HIP_PATH_PLAIN;
+  if (e && e->tree.on && mode >= 0 && mode < 3) {
+    if (e->tree.pair[(mode + 2) % 3].on) path = CALS_HIP_PATH_SECOND;
+    else if (e->tree.pair[mode].on) path = CALS_HIP_PATH_FIRST;
+  }
+  return cals_hip_debug_mttkrp_path(e, mode, path, G_host);
+}
+
+int cals_hip_debug_mttkrp_path(cals_hip_engine *e, int mode, int path, double *G_host) {
   if (!e || !G_host || mode < 0 || mode >= e->n_modes) return CALS_HIP_ERR_ARG;
   if (!e->has_tensor) return fail(e, CALS_HIP_ERR_STATE, "set_tensor first");
   if (e->registry.empty()) return fail(e, CALS_HIP_ERR_STATE, "no model in flight");
+  if (path != CALS_HIP_PATH_PLAIN && path != CALS_HIP_PATH_FIRST && path != CALS_HIP_PATH_SECOND)
+    return fail(e, CALS_HIP_ERR_ARG, "unknown MTTKRP path");
+  if (path == CALS_HIP_PATH_FIRST && !(e->tree.on && e->tree.pair[mode].on))
+    return fail(e, CALS_HIP_ERR_STATE, "this mode is not the first of a dimension-tree pair");
+  if (path == CALS_HIP_PATH_SECOND && !(e->tree.on && e->tree.pair[(mode + 2) % 3].on))
+    return fail(e, CALS_HIP_ERR_STATE, "this mode is not the second of a dimension-tree pair");
   const int64_t R = e->end;
   Geo g;
   int rc;
-  if (e->tree.on && mode == e->tree.second) {
+  if (path == CALS_HIP_PATH_SECOND) {
     // through the tree pair: T from the current factors, then the contraction into a scratch buffer
     const int64_t I = e->modes[mode];
-    if ((rc = launch_ttm(e, R, &g))) return rc;
+    if ((rc = launch_ttm(e, (mode + 2) % 3, R, &g))) return rc;
     void *scratch = nullptr;
     HIPCHK(hipMalloc(&scratch, (size_t)(I * R) * e->es));
-    if ((rc = launch_contract(e, R, scratch))) return rc;
+    rc = launch_contract(e, R, scratch);
+    tree_invalidate(e);
+    if (rc) return rc;
     std::vector<float> hf;
     if (e->dtype == CALS_F32) hf.resize((size_t)(I * R));
     HIPCHK(hipMemcpyAsync(e->dtype == CALS_F32 ? (void *)hf.data() : (void *)G_host, scratch,
@@ -1245,10 +1321,12 @@ int cals_hip_debug_mttkrp(cals_hip_engine *e, int mode, double *G_host) {
     HIPCHK(hipFree(scratch));
     return CALS_HIP_OK;
   }
-  if (e->tree.on && mode == e->tree.first)
-    rc = launch_ttm(e, R, &g);
-  else
+  if (path == CALS_HIP_PATH_FIRST) {
+    rc = launch_ttm(e, mode, R, &g);
+    tree_invalidate(e);
+  } else {
     rc = launch_mttkrp(e, mode, R, &g);
+  }
   if (rc) return rc;
   const ModeLayout &L = e->lay[mode];
   const size_t tile = (size_t)L.ldPart * CALS_BN;

@@ -161,6 +161,7 @@ struct LsArgs {
   int interval;
   double step;            // 0 => cbrt(iters)
   long long max_iter;
+  int *changed;           // ls_kernel: set to 1 when any model's factors were rewritten (may be null)
 };
 hipError_t ls_snapshot_launch(const LsArgs &a, hipStream_t st);  // cals.cpp:203-211
 hipError_t ls_launch(const LsArgs &a, hipStream_t st);           // cals.cpp:310-331

@@ -618,6 +618,7 @@ __global__ void __launch_bounds__(256) ls_kernel(const LsArgs a) {
   if (tid == 0) {
     a.mt.ls_iter[slot] = ls_iter;
     a.mt.flags[slot] = flags;
+    if (flags && a.changed) atomicOr(a.changed, 1);
   }
   (void)s_lam;
 }

@@ -107,11 +107,14 @@ int cals_hip_create(cals_hip_engine **out, int n_modes, const int64_t *modes, in
 int cals_hip_create_ex(cals_hip_engine **out, int n_modes, const int64_t *modes,
                        int64_t buffer_size, int device, int dtype);
 int cals_hip_dtype(const cals_hip_engine *e);
-/* MTTKRP plan of a 3-way engine, fixed at create: 0 = three fused MTTKRPs per sweep
- * (mttkrp::MTTKRP semantics, src/utils/mttkrp.cpp:218-328); 1 = modes 0 and 1 share T = X x_2 C
- * (dimension tree "A"); 2 = modes 1 and 2 share T = X x_0 A (tree "B") -- the reference's two-step
- * association (mttkrp.cpp:330-560) with the TTM reused by two modes.  Chosen by a cost model;
- * CALS_HIP_TREE=0|A|B in the environment at create overrides it. */
+/* MTTKRP plan of a 3-way engine, fixed at create.  0 = three fused MTTKRPs per sweep
+ * (mttkrp::MTTKRP semantics, src/utils/mttkrp.cpp:218-328).  Dimension-tree plans use the
+ * reference's two-step association (mttkrp.cpp:330-560) with the TTM T = X x_a P shared by the two
+ * modes updated while factor a stays fixed: 1 ("A") = modes 0,1 share X x_2 C; 2 ("B") = modes 1,2
+ * share X x_0 A; 3 ("M", multi-sweep) = every TTM serves two consecutive updates of the sequence
+ * A B C A B C ..., also across the sweep boundary (3 TTMs per 2 sweeps); a T that a line-search
+ * step, an eviction or an admission made stale is dropped and recomputed.  Chosen by a cost model;
+ * CALS_HIP_TREE=0|A|B|M in the environment at create overrides it. */
 int cals_hip_tree(const cals_hip_engine *e);
 int cals_hip_destroy(cals_hip_engine *e);
 const char *cals_hip_last_error(const cals_hip_engine *e);
@@ -160,6 +163,14 @@ int cals_hip_synchronize(cals_hip_engine *e);
 /* MTTKRP of the current multi-factor block for `mode` (mttkrp::mttkrp, src/utils/mttkrp.cpp:562)
  * into G_host (I_mode x active_cols, ld = I_mode) WITHOUT touching the engine state. */
 int cals_hip_debug_mttkrp(cals_hip_engine *e, int mode, double *G_host);
+/* Same through an explicit path: PLAIN = fused MTTKRP kernel; FIRST = as the first mode of a
+ * dimension-tree pair (TTM kernel, G fused); SECOND = as the second mode (TTM of the previous mode
+ * from the current factors, then the contraction kernel).  CALS_HIP_ERR_STATE if the engine's plan
+ * has no such path for this mode. */
+#define CALS_HIP_PATH_PLAIN 0
+#define CALS_HIP_PATH_FIRST 1
+#define CALS_HIP_PATH_SECOND 2
+int cals_hip_debug_mttkrp_path(cals_hip_engine *e, int mode, int path, double *G_host);
 /* Copy multi-factor `mode` (I_mode x active_cols) / lambda (active_cols) / the column-indexed
  * Gramian store (CALS_HIP_MAX_RANK x active_cols per mode) to the host. */
 int cals_hip_debug_get_factor(cals_hip_engine *e, int mode, double *host);

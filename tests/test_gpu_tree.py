@@ -11,10 +11,10 @@ from helpers import make_models, reconstruct, rel
 from test_gpu_parity import TOL_KERNEL, TOL_RUN, _assert_models_match, _run_both, engine_with
 
 pytestmark = pytest.mark.gpu
-PLANS = {"0": 0, "A": 1, "B": 2}
+PLANS = {"0": 0, "A": 1, "B": 2, "M": 3}
 
 
-@pytest.fixture(params=["A", "B", "0"])
+@pytest.fixture(params=["M", "A", "B", "0"])
 def plan(request):
     old = os.environ.get("CALS_HIP_TREE")
     os.environ["CALS_HIP_TREE"] = request.param
@@ -50,8 +50,18 @@ def test_tree_mttkrp_every_mode_vs_oracle(cc, oracle, inputs, plan, modes, ranks
     e.admit()
     facs = [np.asfortranarray(np.hstack([fs[n] for fs, _, _ in base])) for n in range(3)]
     tol = TOL_KERNEL if dtype == "f64" else 2e-5
+    pairs = {"0": [], "A": [0], "B": [1], "M": [0, 1, 2]}[plan]
     for n in range(3):
-        assert rel(e.debug_mttkrp(n), oracle.mttkrp(X, modes, facs, n, oracle.MTTKRP)) < tol
+        want = oracle.mttkrp(X, modes, facs, n, oracle.MTTKRP)
+        assert rel(e.debug_mttkrp(n), want) < tol
+        assert rel(e.debug_mttkrp(n, "plain"), want) < tol
+        if n in pairs:
+            assert rel(e.debug_mttkrp(n, "first"), want) < tol          # TTM kernel, fused G
+        else:
+            with pytest.raises(cc.CalsHipError):
+                e.debug_mttkrp(n, "first")
+        if (n + 2) % 3 in pairs:
+            assert rel(e.debug_mttkrp(n, "second"), want) < tol         # T of the pair + contraction
     e.close()
 
 
@@ -59,7 +69,7 @@ def test_auto_plan_prefers_a_tree_for_the_baseline_shapes(cc):
     old = os.environ.pop("CALS_HIP_TREE", None)
     try:
         e = cc.Engine([300, 300, 300], 2656)
-        assert e.tree in (1, 2)
+        assert e.tree == 3        # cube: every pair costs the same, 3 TTMs per 2 sweeps
         e.close()
         e = cc.Engine([299, 301, 41], 5328, dtype="f32")
         assert e.tree == 2        # contract over the 299-mode; T is J*K*R = 263 MB
@@ -139,6 +149,8 @@ def test_full_size_c3_tree_identities(cc, inputs, plan):
     e.admit()
     X3 = X.reshape(modes, order="F")
     G = [e.debug_mttkrp(n) for n in range(3)]
+    if plan == "M":  # default path under M is "second" for every mode; also check one fused G
+        assert rel(e.debug_mttkrp(2, "first")[:, 0], X3.sum(axis=(0, 1))) < 1e-12
     assert rel(G[0][:, 0], X3.sum(axis=(1, 2))) < 1e-12
     assert rel(G[1][:, 0], X3.sum(axis=(0, 2))) < 1e-12
     assert rel(G[2][:, 0], X3.sum(axis=(0, 1))) < 1e-12
