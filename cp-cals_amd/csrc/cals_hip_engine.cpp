@@ -401,7 +401,8 @@ Geo tree_geometry(const cals_hip_engine *e, int first, int64_t R) {
   const int second = (first + 1) % 3;
   Geo g;
   g.NB = (int)((R + CALS_BN - 1) / CALS_BN);
-  long long T = e->n_cu / std::max(1, g.NB * pc.m_blocks);
+  (void)pc;  // a workgroup walks all M blocks of the pair: the team splits s only
+  long long T = e->n_cu / std::max(1, g.NB);
   if (T < 1) T = 1;
   if (T > e->modes[second]) T = e->modes[second];
   g.T = (int)T;
@@ -435,7 +436,7 @@ int launch_ttm(cals_hip_engine *e, int first, int64_t R, Geo *geo_out) {
   a.NB = g.NB;
   a.T = g.T;
   a.ldPart = L.ldPart;
-  a.grid = g.NB * g.T * pc.m_blocks;
+  a.grid = g.NB * g.T;
   {
     // P panels of one locality group: <= 2 MB of an XCD's 4 MB L2 (CALS_TTM_NBW overrides)
     const size_t panel = (size_t)L.Ap * CALS_BN * e->es;

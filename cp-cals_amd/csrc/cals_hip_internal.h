@@ -64,7 +64,7 @@ struct TtmArgs {
   int Mp, Ap, R;
   int NB, T;         // column blocks, team size (workgroups per column block and M block; split s)
   int ldPart;
-  int grid;          // NB * T * m_blocks workgroups (1-D)
+  int grid;          // NB * T workgroups (1-D); each walks all m_blocks M blocks
   int nbw;           // column blocks per XCD-locality group (ttm_kernel's workgroup mapping)
   int m_blocks, k_big, MT;  // M blocks: the first k_big are MT tiles high, the others MT - 1
   int dbg;           // timing experiments (CALS_TTM_DBG): 1 = skip the T stores, 2 = no stagger

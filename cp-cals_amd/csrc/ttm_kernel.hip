@@ -389,29 +389,32 @@ __global__ void __launch_bounds__(512, 2) ttm_kernel(const TtmArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   // Workgroup -> (column block nb, team member tm, M block by).  XCD-aware bijective remap first
   // (workgroups with equal blockIdx % 8 share an XCD and get consecutive p), then p enumerates
-  // groups of `nbw` column blocks; inside a group all (tm, by) pairs, column block fastest.  One
+  // groups of `nbw` column blocks; inside a group all team members tm, column block fastest.  One
   // XCD's ~grid/8 consecutive p therefore touch few distinct P panels (nbw * Ap * 128 elements fit
-  // its 4 MB L2 and are re-read once per s) and few distinct (tm, by), i.e. X slabs, each shared
-  // by the nbw workgroups that stream it at the same time.
+  // its 4 MB L2 and are re-read once per s) and few distinct tm, i.e. X slabs, each shared by the
+  // nbw workgroups that stream it at the same time.
   const int G = a.grid;
   const int b = blockIdx.x;
   const int xcd = b & 7, q8 = G >> 3, r8 = G & 7;
   const int p = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (b >> 3);
-  const int TY = a.T * a.m_blocks;
-  const int g = p / (a.nbw * TY);
+  const int g = p / (a.nbw * a.T);
   const int wg = min(a.nbw, a.NB - g * a.nbw);
-  const int rem = p - g * a.nbw * TY;
-  const int ty = rem / wg;
-  const int nb = g * a.nbw + (rem - ty * wg);
-  const int tm = ty / a.m_blocks;
-  const int by = ty - tm * a.m_blocks;
-  if constexpr (MT > 1) {
-    if (by >= a.k_big) {
-      TtmBody<MT - 1, T>::run(a, 16 * (a.k_big * MT + (by - a.k_big) * (MT - 1)), tm, nb, lds_raw);
-      return;
+  const int rem = p - g * a.nbw * a.T;
+  const int tm = rem / wg;
+  const int nb = g * a.nbw + (rem - tm * wg);
+  // One workgroup walks ALL M blocks of its (column block, s range), one after the other: blocks
+  // of MT and MT - 1 tiles then cost every workgroup the same (an M block per workgroup left the
+  // CUs that drew an MT - 1 block idle for 1/MT of the kernel).
+  for (int by = 0; by < a.m_blocks; ++by) {
+    if (by > 0) __syncthreads();  // every wave has left the LDS ring of the previous block
+    if constexpr (MT > 1) {
+      if (by >= a.k_big) {
+        TtmBody<MT - 1, T>::run(a, 16 * (a.k_big * MT + (by - a.k_big) * (MT - 1)), tm, nb, lds_raw);
+        continue;
+      }
     }
+    TtmBody<MT, T>::run(a, 16 * by * MT, tm, nb, lds_raw);
   }
-  TtmBody<MT, T>::run(a, 16 * by * MT, tm, nb, lds_raw);
 }
 
 template <int MT, typename T>
