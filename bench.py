@@ -168,10 +168,14 @@ def main():
                         "avg_launch_ms": round(ks.contract_ms / ks.contract_launches, 4),
                         "achieved_GBps": round(ks.contract_bytes / (ks.contract_ms * 1e-3) * 1e-9, 1),
                         "bound": "hbm", "peak_GBps": 8000}
+        # HBM bytes per launch of the dominant kernel from the PMC passes (profiles/traffic.json:
+        # {workload: {kernel: bytes}}; rocprofv3 cannot run inside this process)
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get(args.workload)
+            per_kernel = json.load(open(tpath)).get(args.workload)
+            if isinstance(per_kernel, dict):
+                traffic = per_kernel.get(dom.split(" ")[0])
         out = {
             "metric": "ALS iterations/sec (all concurrent models)",
             "value": round(value, 3), "unit": "ALS it/s", "n_gpus": world, "steps": args.steps,

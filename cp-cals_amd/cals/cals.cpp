@@ -20,7 +20,8 @@ void CalsParams::print() const {
   cout << "Buffer Size:     " << buffer_size << endl;
   cout << "Line Search:     " << (line_search ? "true" : "false") << endl;
   if (line_search) cout << "-Line Search Interval: " << line_search_interval << " iterations" << endl;
-  cout << "Device path:     MI355X HIP engine (device " << device << ")" << endl;
+  cout << "Device path:     MI355X HIP engine (device " << device << ", "
+       << (precision == FP32 ? "fp32" : "fp64") << " storage)" << endl;
   cout << "---------------------------------------" << endl;
 }
 
@@ -95,7 +96,8 @@ CalsReport cp_cals(const Tensor &X, KtensorQueue &kt_queue, CalsParams &p) {
 
   std::vector<int64_t> modes(X.get_modes().begin(), X.get_modes().end());
   EngineGuard g;
-  int rc = cals_hip_create(&g.e, (int)modes.size(), modes.data(), (int64_t)p.buffer_size, p.device);
+  int rc = cals_hip_create_ex(&g.e, (int)modes.size(), modes.data(), (int64_t)p.buffer_size, p.device,
+                              p.precision == CalsParams::FP32 ? CALS_HIP_F32 : CALS_HIP_F64);
   if (rc) fail(g.e, "cals_hip_create", rc);
   if ((rc = cals_hip_set_tensor(g.e, X.get_data()))) fail(g.e, "cals_hip_set_tensor", rc);
   cals_hip_params hp;

@@ -339,6 +339,10 @@ struct CalsParams {
   bool force_max_iter{false};
   bool always_evict_first{false};
   int device{0};  // added: HIP device ordinal (default preserves single-GPU behaviour)
+  // added: storage/arithmetic type on the device, FP64 (the reference's) or FP32 (BASELINE config 4:
+  // fp32 tensor copies, factors and MFMA; Gramians, solves, lambda, error stay fp64)
+  enum PRECISION { FP64 = 0, FP32 = 1 };
+  PRECISION precision{FP64};
   void print() const;
 };
 

@@ -1,5 +1,5 @@
 // CLI demo on the C++ layer, with the options of the reference's src/examples/driver.cpp
-// (-n threads [ignored: no host BLAS], -c MIN:MAX:COPIES, -t I-J-K) plus -d DEVICE:
+// (-n threads [ignored: no host BLAS], -c MIN:MAX:COPIES, -t I-J-K) plus -d DEVICE and -p f64|f32:
 // fits COPIES models of every rank MIN..MAX to a random tensor with concurrent ALS on the GPU and,
 // for comparison, one model at a time (cp_als, same engine), and prints both times.
 #include <iostream>
@@ -26,10 +26,11 @@ static void split(const std::string &s, std::vector<dim_t> &out, char sep) {
 int main(int argc, char **argv) {
   std::vector<dim_t> modes = {210, 210, 210};
   int min_c = 1, max_c = 10, copies = 5, device = 0;
+  bool f32 = false;
   for (int i = 1; i < argc; ++i) {
     const std::string arg = argv[i];
     if ((arg == "-h") || (arg == "--help")) {
-      cout << "Usage: " << argv[0] << " [-n THREADS] [-c MIN:MAX:COPIES] [-t I-J-K] [-d DEVICE]" << endl;
+      cout << "Usage: " << argv[0] << " [-n THREADS] [-c MIN:MAX:COPIES] [-t I-J-K] [-d DEVICE] [-p f64|f32]" << endl;
       return 0;
     } else if ((arg == "-n" || arg == "--nthreads") && i + 1 < argc) {
       ++i;  // host BLAS threads: meaningless on the device path
@@ -53,6 +54,13 @@ int main(int argc, char **argv) {
       modes = v;
     } else if ((arg == "-d" || arg == "--device") && i + 1 < argc) {
       device = (int)std::strtol(argv[++i], nullptr, 10);
+    } else if ((arg == "-p" || arg == "--precision") && i + 1 < argc) {
+      const std::string v = argv[++i];
+      if (v != "f64" && v != "f32") {
+        cerr << "--precision takes f64 or f32." << endl;
+        return 1;
+      }
+      f32 = (v == "f32");
     } else {
       cerr << "Unrecognized argument " << arg << endl;
       return 1;
@@ -76,6 +84,7 @@ int main(int argc, char **argv) {
   cp.max_iterations = 1000;
   cp.tol = 1e-5;
   cp.device = device;
+  cp.precision = f32 ? cals::CalsParams::FP32 : cals::CalsParams::FP64;
   cp.buffer_size = std::accumulate(components.cbegin(), components.cend(), (dim_t)0);
   cp.print();
   cals::Timer t_cals, t_als;

@@ -251,10 +251,11 @@ def test_cpp_api_jk_cp_cals():
     assert r.returncode == 0, r.stdout + r.stderr
 
 
-def test_cli_driver_runs():
+@pytest.mark.parametrize("extra", [[], ["-p", "f32"]])
+def test_cli_driver_runs(extra):
     exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cp-cals_amd", "examples", "driver")
     import subprocess
-    r = subprocess.run([exe, "-t", "30-25-20", "-c", "1:4:3"], capture_output=True, text=True, timeout=300)
+    r = subprocess.run([exe, "-t", "30-25-20", "-c", "1:4:3"] + extra, capture_output=True, text=True, timeout=300)
     print(r.stdout, r.stderr)
     assert r.returncode == 0 and "Speedup:" in r.stdout
 
