@@ -519,10 +519,87 @@ __global__ void __launch_bounds__(256) contract_kernel(const E *Tb, long long S,
   }
 }
 
+// The same with 16-byte loads and four s rows in flight per wave (more bytes outstanding per CU);
+// used when a row fits NI passes of 64 lanes x 16 B.  Summation order per (s, c): lane-strided
+// partial sums in fp64, then the butterfly -- fixed, so results are deterministic.
+template <typename E, int NI>
+__global__ void __launch_bounds__(256) contract4_kernel(const E *Tb, long long S, int Mp, int M,
+                                                        const E *F, long long ldF, E *out,
+                                                        long long ldOut) {
+  constexpr int VE = 16 / (int)sizeof(E);
+  typedef E vec __attribute__((ext_vector_type(VE)));
+  const int c = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double f[NI][VE];
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int v = 0; v < VE; ++v) {
+      const int m = (lane + 64 * i) * VE + v;
+      f[i][v] = (m < M) ? (double)F[m + ldF * c] : 0.0;
+    }
+  const E *Tc = Tb + (long long)c * S * Mp;
+  for (long long s0 = 4 * (blockIdx.y * 4 + wave); s0 < S; s0 += 16 * gridDim.y) {
+    vec x[4][NI];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const long long s = (s0 + k < S) ? s0 + k : S - 1;  // clamped rows are computed and dropped
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const int m0 = (lane + 64 * i) * VE;
+        if (m0 < Mp)
+          x[k][i] = __builtin_nontemporal_load(reinterpret_cast<const vec *>(Tc + s * Mp + m0));
+        else
+          x[k][i] = (vec)(E)0;
+      }
+    }
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int v = 0; v < VE; ++v) acc[k] += (double)x[k][i][v] * f[i][v];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) acc[k] += __shfl_xor(acc[k], off, 64);
+    if (lane < 4 && s0 + lane < S) {
+      const double r = lane == 0 ? acc[0] : lane == 1 ? acc[1] : lane == 2 ? acc[2] : acc[3];
+      out[s0 + lane + ldOut * c] = (E)r;
+    }
+  }
+}
+
+template <typename E>
+static bool contract4_try(const E *Tb, long long S, int Mp, int M, const E *F, long long ldF, E *out,
+                          long long ldOut, int R, hipStream_t st) {
+  constexpr int VE = 16 / (int)sizeof(E);
+  const int passes = (Mp + 64 * VE - 1) / (64 * VE);
+  if (passes > 4) return false;
+  int gy = (int)((S / 4 + 15) / 16);
+  if (gy < 1) gy = 1;
+  const dim3 grid(R, gy), block(256);
+  switch (passes) {
+    case 1: hipLaunchKernelGGL((contract4_kernel<E, 1>), grid, block, 0, st, Tb, S, Mp, M, F, ldF, out, ldOut); break;
+    case 2: hipLaunchKernelGGL((contract4_kernel<E, 2>), grid, block, 0, st, Tb, S, Mp, M, F, ldF, out, ldOut); break;
+    case 3: hipLaunchKernelGGL((contract4_kernel<E, 3>), grid, block, 0, st, Tb, S, Mp, M, F, ldF, out, ldOut); break;
+    default: hipLaunchKernelGGL((contract4_kernel<E, 4>), grid, block, 0, st, Tb, S, Mp, M, F, ldF, out, ldOut); break;
+  }
+  return true;
+}
+
 hipError_t contract_launch(const void *Tb, long long S, int Mp, int M, const void *F,
                            long long ldF, void *out, long long ldOut, int R, int dtype,
                            hipStream_t st) {
   if (R <= 0) return hipSuccess;
+  if (dtype == CALS_F32) {
+    if (contract4_try<float>((const float *)Tb, S, Mp, M, (const float *)F, ldF, (float *)out, ldOut, R, st))
+      return hipGetLastError();
+  } else if (contract4_try<double>((const double *)Tb, S, Mp, M, (const double *)F, ldF,
+                                   (double *)out, ldOut, R, st)) {
+    return hipGetLastError();
+  }
   int gy = (int)((S + 63) / 64);  // >= 16 s values per wave
   if (gy < 1) gy = 1;
   const dim3 grid(R, gy), block(256);
