@@ -48,7 +48,8 @@ struct TtmCfg {
   static constexpr int BUF = POFF + 16 * PP;
   static constexpr int SP = 144 / ES;                // staging tile pitch: 18 f64 | 36 f32 per column
   static constexpr int STG = 16 * SP;                // per-wave staging tile (T flush transpose)
-  static constexpr int LDS_BYTES = (3 * BUF + 8 * STG) * ES;
+  static constexpr int LDS_BYTES = (3 * BUF + (ES == 4 ? 8 * STG : 0)) * ES;  // staging: fp32 only
+  static constexpr int NQ = (ES == 8) ? 4 : 1;       // Q values a lane needs per s (see TtmBody)
   static constexpr int N = 4 * MT;                   // MFMAs per slab per wave
   static constexpr int RING = (ES == 4) ? 8 : 6;
   static constexpr int D = N < RING ? N : RING;      // operand ring depth
@@ -68,7 +69,11 @@ struct TtmPipe {
     asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(outstanding));
     __builtin_amdgcn_sched_barrier(0);
     constexpr int q = I / MT, t = I % MT;
-    acc[t] = Acc<T>::mfma(ring[I % C::D], bq[q], acc[t]);
+    // fp64: operands swapped, the tile comes out transposed (TtmBody comment)
+    if constexpr (C::ES == 8)
+      acc[t] = Acc<T>::mfma(bq[q], ring[I % C::D], acc[t]);
+    else
+      acc[t] = Acc<T>::mfma(ring[I % C::D], bq[q], acc[t]);
     if constexpr (I + C::D < C::N) {
       constexpr int qn = (I + C::D) / MT, tn = (I + C::D) % MT;
       lds_read_off<T, ((4 * qn) * C::LDL + 16 * tn) * C::ES>(ring[I % C::D], base);
@@ -202,12 +207,31 @@ static __device__ __forceinline__ void run(const TtmArgs &a, const int m0, const
 
   const unsigned lane_off = (unsigned)((krow * C::LDL + lcol) * C::ES);
   const unsigned lds0 = (unsigned)(size_t)((LDS_AS const char *)lds_raw);
-  const unsigned q_lane_off = (unsigned)((C::QOFF + wave * 16 + lcol) * C::ES);
+  // Accumulator layouts.  fp32: acc[t][r] = T[m = 16t + 4 krow + r][c = lcol] (X as the MFMA's A
+  // operand, P as B).  fp64: the operands are SWAPPED (P as A, X as B; both operand layouts hold
+  // element (k = lane>>4, index = lane&15), so the registers are the same) and the tile comes out
+  // transposed: acc[t][r] = T[m = 16t + lcol][c = krow + 4r].  For a fixed register the 16 lanes of
+  // a krow group then hold 16 consecutive m of one column = one whole 128-byte line, so the T flush
+  // and the partial-tile epilogue store full lines straight from registers.  (Stores from the
+  // untransposed fp64 layout cover a quarter line per column and make the L2 fetch every line
+  // before merging it: rocprofv3 FETCH_SIZE showed 2.0 GB of fills per launch at C3.)
+  const unsigned q_lane_off =
+      (unsigned)((C::QOFF + wave * 16 + (C::ES == 8 ? krow : lcol)) * C::ES);
   const unsigned p_lane_off = (unsigned)((C::POFF + krow * C::PP + wave * 16 + lcol) * C::ES);
-  // ---- T flush through a per-wave LDS staging tile, so that every global store instruction writes
-  // whole 128-byte lines (8 lanes x 16 B per column).  Stores straight from the MFMA register layout
-  // cover a quarter (fp64) or half (fp32) line per instruction and make the L2 fetch each line
-  // before merging it: measured with rocprofv3 FETCH_SIZE, 2.0 GB of fills per launch at C3.
+  T *const Tout = static_cast<T *>(a.Tout);
+  const bool st = !(a.dbg & 1);
+
+  // fp64: per register r the column krow + 4r of this wave
+  T *tc[4];
+  bool cv[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int gc = nb * CALS_BN + wave * 16 + krow + 4 * r;
+    cv[r] = gc < a.R && st;
+    tc[r] = Tout + ((long long)(gc < a.R ? gc : 0) * S) * a.Mp + m0 + lcol;
+  }
+  // fp32: T flush through a per-wave LDS staging tile (two tiles = 32 rows = one 128-byte line per
+  // column), so that every global_store_dwordx4 writes 8 whole lines
   T *const stg = lds + 3 * C::BUF + wave * C::STG;
   const int j8 = lane & 7;
   T *tb[2];
@@ -216,34 +240,28 @@ static __device__ __forceinline__ void run(const TtmArgs &a, const int m0, const
   for (int h = 0; h < 2; ++h) {
     const int c8 = (lane >> 3) + 8 * h;
     const int gc = nb * CALS_BN + wave * 16 + c8;
-    tv[h] = gc < a.R;
-    tb[h] = static_cast<T *>(a.Tout) + ((long long)(tv[h] ? gc : 0) * S) * a.Mp + m0 + (16 / C::ES) * j8;
+    tv[h] = gc < a.R && st;
+    tb[h] = Tout + ((long long)(gc < a.R ? gc : 0) * S) * a.Mp + m0 + 4 * j8;
   }
   // fp32, odd MT: the last tile alone (16 rows = 64 B per column, 4 lanes per column)
   const int gc4 = nb * CALS_BN + wave * 16 + (lane >> 2);
-  const bool tv4 = gc4 < a.R;
-  T *const tb4 = static_cast<T *>(a.Tout) + ((long long)(tv4 ? gc4 : 0) * S) * a.Mp + m0 + 4 * (lane & 3);
+  const bool tv4 = gc4 < a.R && st;
+  T *const tb4 = Tout + ((long long)(gc4 < a.R ? gc4 : 0) * S) * a.Mp + m0 + 4 * (lane & 3);
 
-  // end of an s: G += T * Q[s, c]; T -> HBM; T = 0
-  auto flush = [&](long long s, T qv) {
+  // end of an s: G += T * Q[s, c]; T -> HBM (non-temporal: written once, read once by the
+  // contraction); T = 0
+  auto flush = [&](long long s, const T (&qv)[C::NQ]) {
     asm volatile("" ::: "memory");
     const long long so = s * a.Mp;
-    const bool st = !(a.dbg & 1);
     if constexpr (C::ES == 8) {
-      typedef double v2d __attribute__((ext_vector_type(2)));
 #pragma unroll
       for (int t = 0; t < MT; ++t) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          gacc[t][r] += tacc[t][r] * qv;
-          stg[lcol * C::SP + krow + 4 * r] = tacc[t][r];
+          gacc[t][r] += tacc[t][r] * qv[r];
+          if (cv[r]) __builtin_nontemporal_store(tacc[t][r], tc[r] + so + 16 * t);
         }
         tacc[t] = (acc_t){0, 0, 0, 0};
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const v2d v = *reinterpret_cast<const v2d *>(stg + ((lane >> 3) + 8 * h) * C::SP + 2 * j8);
-          if (tv[h] && st) __builtin_nontemporal_store(v, reinterpret_cast<v2d *>(tb[h] + so + 16 * t));
-        }
       }
     } else {
 #pragma unroll
@@ -251,24 +269,24 @@ static __device__ __forceinline__ void run(const TtmArgs &a, const int m0, const
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) gacc[t + k][r] += tacc[t + k][r] * qv;
+          for (int r = 0; r < 4; ++r) gacc[t + k][r] += tacc[t + k][r] * qv[0];
           *reinterpret_cast<acc_t *>(stg + lcol * C::SP + 16 * k + 4 * krow) = tacc[t + k];
           tacc[t + k] = (acc_t){0, 0, 0, 0};
         }
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           const acc_t v = *reinterpret_cast<const acc_t *>(stg + ((lane >> 3) + 8 * h) * C::SP + 4 * j8);
-          if (tv[h] && st) __builtin_nontemporal_store(v, reinterpret_cast<acc_t *>(tb[h] + so + 16 * t));
+          if (tv[h]) __builtin_nontemporal_store(v, reinterpret_cast<acc_t *>(tb[h] + so + 16 * t));
         }
       }
       if constexpr (MT % 2 == 1) {
         constexpr int t = MT - 1;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) gacc[t][r] += tacc[t][r] * qv;
+        for (int r = 0; r < 4; ++r) gacc[t][r] += tacc[t][r] * qv[0];
         *reinterpret_cast<acc_t *>(stg + lcol * C::SP + 4 * krow) = tacc[t];
         tacc[t] = (acc_t){0, 0, 0, 0};
         const acc_t v = *reinterpret_cast<const acc_t *>(stg + (lane >> 2) * C::SP + 4 * (lane & 3));
-        if (tv4 && st) __builtin_nontemporal_store(v, reinterpret_cast<acc_t *>(tb4 + so + 16 * t));
+        if (tv4) __builtin_nontemporal_store(v, reinterpret_cast<acc_t *>(tb4 + so + 16 * t));
       }
     }
     asm volatile("" ::: "memory");
@@ -279,7 +297,7 @@ static __device__ __forceinline__ void run(const TtmArgs &a, const int m0, const
   auto unit_loop = [&]<bool LATE>() {
     bool pend = false;       // LATE: flush of the previous unit deferred behind this unit's barrier
     long long s_pend = 0;
-    T q_pend = 0;
+    T q_pend[C::NQ] = {};
     for (long long iu = 0; iu < n_units; ++iu) {
       const int buf_n = (buf == 2) ? 0 : buf + 1;
       const int buf_nn = (buf_n == 2) ? 0 : buf_n + 1;
@@ -304,9 +322,14 @@ static __device__ __forceinline__ void run(const TtmArgs &a, const int m0, const
         }
       }
       T ring[C::D];
-      T qcur;
+      T qcur[C::NQ];
       T bq[4];
-      lds_read<T>(qcur, bufb + q_lane_off);
+      lds_read_off<T, 0>(qcur[0], bufb + q_lane_off);
+      if constexpr (C::NQ == 4) {  // fp64: Q[s, krow + 4r]
+        lds_read_off<T, 4 * C::ES>(qcur[1], bufb + q_lane_off);
+        lds_read_off<T, 8 * C::ES>(qcur[2], bufb + q_lane_off);
+        lds_read_off<T, 12 * C::ES>(qcur[3], bufb + q_lane_off);
+      }
       lds_read_off<T, 0>(bq[0], bufb + p_lane_off);
       lds_read_off<T, 4 * C::PP * C::ES>(bq[1], bufb + p_lane_off);
       lds_read_off<T, 8 * C::PP * C::ES>(bq[2], bufb + p_lane_off);
@@ -347,7 +370,8 @@ static __device__ __forceinline__ void run(const TtmArgs &a, const int m0, const
         if constexpr (LATE) {
           pend = true;
           s_pend = s_c;
-          q_pend = qcur;
+#pragma unroll
+          for (int r = 0; r < C::NQ; ++r) q_pend[r] = qcur[r];
         } else {
           flush(s_c, qcur);
         }
@@ -372,13 +396,16 @@ static __device__ __forceinline__ void run(const TtmArgs &a, const int m0, const
 
   // ---- epilogue: G_first partial tile [ldPart x 128] of (nb, tm)
   T *pt = static_cast<T *>(a.partial) + ((long long)(nb * a.T + tm)) * ((long long)a.ldPart * CALS_BN);
-  const int cl = wave * 16 + lcol;
 #pragma unroll
   for (int t = 0; t < MT; ++t) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int m = m0 + 16 * t + Acc<T>::row(krow, r);
-      pt[m + (long long)a.ldPart * cl] = gacc[t][r];
+      if constexpr (C::ES == 8) {  // transposed tile: 16 lanes = one line of column krow + 4r
+        pt[m0 + 16 * t + lcol + (long long)a.ldPart * (wave * 16 + krow + 4 * r)] = gacc[t][r];
+      } else {
+        const int m = m0 + 16 * t + Acc<T>::row(krow, r);
+        pt[m + (long long)a.ldPart * (wave * 16 + lcol)] = gacc[t][r];
+      }
     }
   }
 }
