@@ -68,7 +68,7 @@ EXPORTS = [
     "cals_hip_debug_get_norms", "cals_hip_set_profiling", "cals_hip_get_kernel_stats",
     "cals_hip_reset_kernel_stats", "cals_hip_stream", "cals_hip_device_count",
     "cals_hip_create_ex", "cals_hip_dtype", "cals_hip_tree", "cals_hip_set_tensor_f32",
-    "cals_hip_debug_clock", "cals_hip_host_first_fit", "cals_hip_host_compress_plan", "cals_hip_host_active_cols",
+    "cals_hip_debug_clock", "cals_hip_debug_ttm_trace", "cals_hip_host_first_fit", "cals_hip_host_compress_plan", "cals_hip_host_active_cols",
 ]
 
 _LIB = None
@@ -87,6 +87,7 @@ def load_library():
     lib.cals_hip_create.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(i64), i64, C.c_int]
     lib.cals_hip_create_ex.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(i64), i64, C.c_int, C.c_int]
     lib.cals_hip_dtype.argtypes = [vp]
+    lib.cals_hip_debug_ttm_trace.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int]
     lib.cals_hip_tree.argtypes = [vp]
     lib.cals_hip_set_tensor_f32.argtypes = [vp, C.POINTER(C.c_float)]
     lib.cals_hip_destroy.argtypes = [vp]

@@ -110,6 +110,7 @@ struct cals_hip_engine {
   void *krp_ws = nullptr;
   size_t krp_elems = 0;
   unsigned long long *dbg_clock = nullptr;  // CALS_MTTKRP_CLOCK=1: in-kernel clock stamps
+  unsigned long long *dbg_trace = nullptr;  // CALS_TTM_TRACE=1 (CALS_DIAG builds): ttm_kernel stage stamps
 
   ModelTable mt{};
   int max_slots = 0;
@@ -448,6 +449,7 @@ int launch_ttm(cals_hip_engine *e, int first, int64_t R, Geo *geo_out) {
   a.k_big = pc.k_big;
   a.MT = pc.MT;
   a.dbg = getenv("CALS_TTM_DBG") ? atoi(getenv("CALS_TTM_DBG")) : 0;
+  a.dbg_trace = e->dbg_trace;
   if ((size_t)g.NB * g.T * (size_t)L.ldPart * CALS_BN > e->partial_elems)
     return fail(e, CALS_HIP_ERR_STATE, "internal: partial buffer too small");
   double total = 1.0;
@@ -1001,6 +1003,9 @@ int cals_hip_create_ex(cals_hip_engine **out, int n_modes, const int64_t *modes,
   size_t ld_max = 0;
   for (int n = 0; n < n_modes; n++) ld_max = std::max<size_t>(ld_max, (size_t)e->lay[n].ldPart);
   e->partial_elems = std::max<size_t>((size_t)2 * e->n_cu, nb_max) * ld_max * CALS_BN;
+  if (getenv("CALS_TTM_TRACE")) {
+    if ((rc = dev_alloc(e, &e->dbg_trace, (size_t)16 * 2048))) return rc;
+  }
   if (getenv("CALS_MTTKRP_CLOCK")) {
     if ((rc = dev_alloc(e, &e->dbg_clock, (size_t)16384))) return rc;
   }
@@ -1067,6 +1072,7 @@ int cals_hip_destroy(cals_hip_engine *e) {
   fr(e->tree.Tbuf);
   fr(e->tree.Pt);
   fr(e->tree.d_changed);
+  fr(e->dbg_trace);
   fr(e->krp_ws);
   fr(e->d_jk_norms);
   fr(e->mt.col);
@@ -1437,6 +1443,14 @@ int cals_hip_reset_kernel_stats(cals_hip_engine *e) {
 }
 
 void *cals_hip_stream(cals_hip_engine *e) { return e ? (void *)e->stream : nullptr; }
+
+int cals_hip_debug_ttm_trace(cals_hip_engine *e, uint64_t *out, int n) {
+  if (!e || !out || n < 1 || n > 16 * 2048) return CALS_HIP_ERR_ARG;
+  if (!e->dbg_trace) return fail(e, CALS_HIP_ERR_STATE, "create the engine with CALS_TTM_TRACE=1");
+  HIPCHK(hipStreamSynchronize(e->stream));
+  HIPCHK(hipMemcpy(out, e->dbg_trace, (size_t)n * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  return CALS_HIP_OK;
+}
 
 int cals_hip_debug_clock(cals_hip_engine *e, int n_workgroups, double *cycles_median, double *ghz_median) {
   if (!e || !e->dbg_clock || n_workgroups < 1 || n_workgroups > 4096) return CALS_HIP_ERR_ARG;

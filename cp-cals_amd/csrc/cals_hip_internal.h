@@ -67,7 +67,9 @@ struct TtmArgs {
   int grid;          // NB * T workgroups (1-D); each walks all m_blocks M blocks
   int nbw;           // column blocks per XCD-locality group (ttm_kernel's workgroup mapping)
   int m_blocks, k_big, MT;  // M blocks: the first k_big are MT tiles high, the others MT - 1
-  int dbg;           // timing experiments (CALS_TTM_DBG): 1 = skip the T stores, 2 = no stagger
+  int dbg;           // CALS_DIAG builds, CALS_TTM_DBG bits: 1 no T stores, 2 no stagger, 4 one X slab
+                     // (L2 hits), 8 no P DMA, 16 no X DMA -- timing experiments, results garbage
+  unsigned long long *dbg_trace;  // CALS_DIAG builds + CALS_TTM_TRACE=1: per-stage clock stamps
 };
 int ttm_max_mt(int dtype);
 hipError_t ttm_launch(const TtmArgs &a, hipStream_t st);

@@ -159,11 +159,12 @@ static __device__ __forceinline__ void run(const TtmArgs &a, const int m0, const
   auto issue_piece = [&]<int K>(const T *src_slab, const T *p_slab, const T *q_row, T *dst) {
     if constexpr (K < C::NP) {
       const int piece = K * 8 + wave;
-      if (piece < C::PIECES)
+      if (piece < C::PIECES && !DIAG(a.dbg & 16))  // CALS_DIAG, dbg 16 (timing only): no X DMA
         __builtin_amdgcn_global_load_lds((const GLOBAL_AS void *)(src_slab + src_off[K]),
                                          (LDS_AS void *)(dst + piece * C::PE), 16, 0, 0);
     } else if constexpr (K < C::NP + C::NPP) {
       constexpr int k = K - C::NP;
+      if (!DIAG(a.dbg & 8))  // CALS_DIAG, dbg 8 (timing only): no P DMA
       __builtin_amdgcn_global_load_lds((const GLOBAL_AS void *)(p_slab + p_src[k]),
                                        (LDS_AS void *)(dst + p_dst[k]), C::PLB, 0, 0);
     } else if (wave < C::QPIECES) {
@@ -219,7 +220,7 @@ static __device__ __forceinline__ void run(const TtmArgs &a, const int m0, const
       (unsigned)((C::QOFF + wave * 16 + (C::ES == 8 ? krow : lcol)) * C::ES);
   const unsigned p_lane_off = (unsigned)((C::POFF + krow * C::PP + wave * 16 + lcol) * C::ES);
   T *const Tout = static_cast<T *>(a.Tout);
-  const bool st = !(a.dbg & 1);
+  const bool st = !DIAG(a.dbg & 1);  // CALS_DIAG, dbg 1 (timing only): no T stores
 
   // fp64: per register r the column krow + 4r of this wave
   T *tc[4];
@@ -293,8 +294,16 @@ static __device__ __forceinline__ void run(const TtmArgs &a, const int m0, const
     __builtin_amdgcn_sched_barrier(0);
   };
 
+  // CALS_DIAG builds: per-stage shader-clock sums (DMA wait, barrier wait, period) over the steady-
+  // state stages of the first M block, for waves 0 and 4 of 8 workgroups (tools/ttm_trace.py)
+  unsigned long long *trace = nullptr;
+  if (DIAG(a.dbg_trace) && m0 == 0 && lane == 0 && (wave & 3) == 0 && (blockIdx.x & 31) == 0 &&
+      blockIdx.x < 256 && n_units <= 512)
+    trace = a.dbg_trace + ((blockIdx.x >> 5) * 2 + (wave >> 2)) * 2048;
+
   int buf = 0;
   auto unit_loop = [&]<bool LATE>() {
+    unsigned long long dg_vm = 0, dg_bar = 0, dg_per = 0, dg_n = 0, dg_last = 0;  // CALS_DIAG sums
     bool pend = false;       // LATE: flush of the previous unit deferred behind this unit's barrier
     long long s_pend = 0;
     T q_pend[C::NQ] = {};
@@ -304,7 +313,8 @@ static __device__ __forceinline__ void run(const TtmArgs &a, const int m0, const
       const unsigned bufb = lds0 + (unsigned)(buf * C::BUF * C::ES);
       const unsigned base = bufb + lane_off;
       const bool fetch = iu + 2 < n_units;
-      const T *src_slab = Xp + (long long)a.Mp * (16 * ab_2) + slab_stride_s * s_2;
+      // CALS_DIAG, dbg 4 (timing only, results garbage): always the same slab => every X DMA hits the L2
+      const T *src_slab = DIAG(a.dbg & 4) ? Xp : Xp + (long long)a.Mp * (16 * ab_2) + slab_stride_s * s_2;
       const T *p_slab = Pt_nb + (long long)(16 * ab_2) * CALS_BN;
       const T *q_row = Qm + s_2;
       T *dst = lds + buf_nn * C::BUF;
@@ -313,9 +323,22 @@ static __device__ __forceinline__ void run(const TtmArgs &a, const int m0, const
         // barrier #iu at the start of slab iu: DMA(iu+1) landed everywhere, slab iu-1 is finished by
         // everybody, so DMA(iu+2) may overwrite its buffer.  The T stores of a flush are issued
         // BEHIND this wait, so they never sit in front of it (vmcnt counts stores too).
+        unsigned long long d0 = 0, d1 = 0, d2 = 0;
+        if (DIAG(trace)) d0 = __builtin_amdgcn_s_memtime();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (DIAG(trace)) d1 = __builtin_amdgcn_s_memtime();
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
+        if (DIAG(trace)) {
+          d2 = __builtin_amdgcn_s_memtime();
+          if (iu >= 3 && ab_c >= 2) {  // steady-state stages only (not the two behind a T flush)
+            dg_vm += d1 - d0;
+            dg_bar += d2 - d1;
+            dg_per += d2 - dg_last;
+            dg_n++;
+          }
+          dg_last = d2;
+        }
         if (pend) {
           flush(s_pend, q_pend);
           pend = false;
@@ -350,9 +373,22 @@ static __device__ __forceinline__ void run(const TtmArgs &a, const int m0, const
       }(std::make_integer_sequence<int, C::H>{});
 
       if constexpr (!LATE) {
+        unsigned long long d0 = 0, d1 = 0, d2 = 0;
+        if (DIAG(trace)) d0 = __builtin_amdgcn_s_memtime();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (DIAG(trace)) d1 = __builtin_amdgcn_s_memtime();
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
+        if (DIAG(trace)) {
+          d2 = __builtin_amdgcn_s_memtime();
+          if (iu >= 3 && ab_c >= 2) {
+            dg_vm += d1 - d0;
+            dg_bar += d2 - d1;
+            dg_per += d2 - dg_last;
+            dg_n++;
+          }
+          dg_last = d2;
+        }
       }
 
       [&]<int... Is>(std::integer_sequence<int, Is...>) {
@@ -387,8 +423,14 @@ static __device__ __forceinline__ void run(const TtmArgs &a, const int m0, const
     if constexpr (LATE) {
       if (pend) flush(s_pend, q_pend);
     }
+    if (DIAG(trace)) {  // stamps stay in registers inside the loop (a global store per stage would sit
+      trace[0] = dg_vm;  // in front of the vmcnt wait it is meant to measure)
+      trace[1] = dg_bar;
+      trace[2] = dg_per;
+      trace[3] = dg_n;
+    }
   };
-  if (wave < 4 && !(a.dbg & 2))
+  if (wave < 4 && !DIAG(a.dbg & 2))
     unit_loop.template operator()<false>();
   else
     unit_loop.template operator()<true>();

@@ -203,6 +203,10 @@ void *cals_hip_stream(cals_hip_engine *e);
 /* diagnostics (CALS_MTTKRP_CLOCK=1 in the environment at create): median over workgroups of the
  * shader cycles a MTTKRP workgroup ran and of the clock (GHz) it saw (s_memtime / s_memrealtime) */
 int cals_hip_debug_clock(cals_hip_engine *e, int n_workgroups, double *cycles_median, double *ghz_median);
+/* diagnostics (library built with CALS_DIAG=1, CALS_TTM_TRACE=1 at create): shader-clock stamps taken
+ * before the DMA wait / before / after the stage barrier by waves 0 and 4 of 8 workgroups of the
+ * last ttm_kernel launch: out[((wg * 2 + group) * 512 + stage) * 4 + {0, 1, 2}] (tools/ttm_trace.py) */
+int cals_hip_debug_ttm_trace(cals_hip_engine *e, uint64_t *out, int n);
 /* number of HIP devices visible (0 when none); never initialises a context on failure */
 int cals_hip_device_count(void);
 
