@@ -106,10 +106,16 @@ def main():
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.dist_backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
+        backend = args.dist_backend
+        if backend == "nccl":
+            try:
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            except Exception as exc:  # control plane only (barrier + max of a scalar): gloo does it too
+                print("rank %d: RCCL process group failed (%s); using gloo" % (rank, exc), file=sys.stderr)
+                backend = "gloo"
+        if backend == "gloo":
             dist.init_process_group("gloo", rank=rank, world_size=world)
+        args.dist_backend = backend
     red_dev = dev if (world == 1 or args.dist_backend == "nccl") else torch.device("cpu")
 
     modes, k_models, ls = WORKLOADS[args.workload]

@@ -29,6 +29,8 @@ def build(force=False, verbose=False):
             extra = ["-DCALS_V3_RING=%s" % os.environ["CALS_V3_RING"]] if os.environ.get("CALS_V3_RING") else []
             if os.environ.get("CALS_DIAG"):
                 extra.append("-DCALS_DIAG=1")
+            if os.environ.get("CALS_TTM_RING"):
+                extra.append("-DCALS_TTM_RING=%s" % os.environ["CALS_TTM_RING"])
             cmd = [hipcc] + FLAGS + extra + ["-x", "hip", "-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd))

@@ -51,7 +51,10 @@ struct TtmCfg {
   static constexpr int LDS_BYTES = (3 * BUF + (ES == 4 ? 8 * STG : 0)) * ES;  // staging: fp32 only
   static constexpr int NQ = (ES == 8) ? 4 : 1;       // Q values a lane needs per s (see TtmBody)
   static constexpr int N = 4 * MT;                   // MFMAs per slab per wave
-  static constexpr int RING = (ES == 4) ? 8 : 6;
+#ifndef CALS_TTM_RING
+#define CALS_TTM_RING 6
+#endif
+  static constexpr int RING = (ES == 4) ? 8 : CALS_TTM_RING;
   static constexpr int D = N < RING ? N : RING;      // operand ring depth
   static constexpr int H = N / 2;                    // barrier position
   static constexpr int NDMA = NP + NPP + 1;          // DMA instructions per wave per stage
