@@ -119,6 +119,10 @@ struct cals_hip_engine {
   std::vector<int> free_slots;
 
   // host mirrors of the per-slot scalars (filled by fetch_status)
+  // fetch_status: pack_status_kernel -> d_status -> one D2H into the pinned h_status
+  StatusRec *d_status = nullptr, *h_status = nullptr;
+  size_t status_cap = 0;
+  bool changed_deferred = false;  // run(): the line-search "changed" flag travels with the status
   std::vector<int> h_flags;
   std::vector<long long> h_iters;
   std::vector<double> h_err, h_fit, h_old_fit;
@@ -503,7 +507,7 @@ LsArgs make_ls_args(cals_hip_engine *e) {
 }
 
 // One sweep over the modes for all in-flight models (src/cals.cpp:203-331) + finish kernel.
-int sweep_once(cals_hip_engine *e, bool evict_enabled) {
+int sweep_once(cals_hip_engine *e, bool evict_enabled, bool defer_changed = false) {
   if (e->registry.empty()) return CALS_HIP_OK;
   int rc = upload_slots(e);
   if (rc) return rc;
@@ -560,7 +564,9 @@ int sweep_once(cals_hip_engine *e, bool evict_enabled) {
     la.changed = pending ? e->tree.d_changed : nullptr;
     HIPCHK(ls_launch(la, e->stream));
     prof_end(e, pk);
-    if (pending) {
+    if (pending && defer_changed) {
+      e->changed_deferred = true;  // cals_hip_run: the flag comes back with the status records
+    } else if (pending) {
       // an extrapolation or a revert rewrote some model's factors: T (contracted with one of them)
       // is stale.  One 4-byte read-back per sweep, only while a T is pending and LS is on.
       int changed = 0;
@@ -587,19 +593,40 @@ int sweep_once(cals_hip_engine *e, bool evict_enabled) {
   return CALS_HIP_OK;
 }
 
+// Status of the in-flight models after a sweep: one tiny kernel packs {flags, iters, err, fit,
+// old_fit} of the registry's slots (+ the line-search "changed" flag) into one buffer, ONE
+// device-to-host copy into pinned memory brings it over, and the host scatters it into the
+// slot-indexed mirrors.  (Five pageable copies of whole slot arrays cost 0.5-1 ms per sweep.)
 int fetch_status(cals_hip_engine *e) {
-  const size_t n = (size_t)e->max_slots;
-  HIPCHK(hipMemcpyAsync(e->h_flags.data(), e->mt.flags, n * sizeof(int), hipMemcpyDeviceToHost,
+  int rc = upload_slots(e);
+  if (rc) return rc;
+  const size_t ns = e->registry.size();
+  if (ns + 1 > e->status_cap) {
+    if (e->d_status) HIPCHK(hipFree(e->d_status));
+    if (e->h_status) HIPCHK(hipHostFree(e->h_status));
+    e->d_status = e->h_status = nullptr;
+    e->status_cap = std::max<size_t>(2 * (ns + 1), 256);
+    HIPCHK(hipMalloc((void **)&e->d_status, e->status_cap * sizeof(StatusRec)));
+    HIPCHK(hipHostMalloc((void **)&e->h_status, e->status_cap * sizeof(StatusRec), hipHostMallocDefault));
+  }
+  HIPCHK(pack_status_launch(e->d_slots, (int)ns, e->mt, e->changed_deferred ? e->tree.d_changed : nullptr,
+                            e->d_status, e->stream));
+  HIPCHK(hipMemcpyAsync(e->h_status, e->d_status, (ns + 1) * sizeof(StatusRec), hipMemcpyDeviceToHost,
                         e->stream));
-  HIPCHK(hipMemcpyAsync(e->h_iters.data(), e->mt.iters, n * sizeof(long long),
-                        hipMemcpyDeviceToHost, e->stream));
-  HIPCHK(hipMemcpyAsync(e->h_err.data(), e->mt.err, n * sizeof(double), hipMemcpyDeviceToHost,
-                        e->stream));
-  HIPCHK(hipMemcpyAsync(e->h_fit.data(), e->mt.fit, n * sizeof(double), hipMemcpyDeviceToHost,
-                        e->stream));
-  HIPCHK(hipMemcpyAsync(e->h_old_fit.data(), e->mt.old_fit, n * sizeof(double),
-                        hipMemcpyDeviceToHost, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
+  if (e->changed_deferred) {
+    if (e->h_status[0].flags) tree_invalidate(e);
+    e->changed_deferred = false;
+  }
+  for (size_t k = 0; k < ns; k++) {
+    const StatusRec &r = e->h_status[1 + k];
+    const size_t slot = (size_t)e->models[e->registry[k]].slot;
+    e->h_flags[slot] = r.flags;
+    e->h_iters[slot] = r.iters;
+    e->h_err[slot] = r.err;
+    e->h_fit[slot] = r.fit;
+    e->h_old_fit[slot] = r.old_fit;
+  }
   return CALS_HIP_OK;
 }
 
@@ -1072,6 +1099,8 @@ int cals_hip_destroy(cals_hip_engine *e) {
   fr(e->tree.Tbuf);
   fr(e->tree.Pt);
   fr(e->tree.d_changed);
+  fr(e->d_status);
+  if (e->h_status) (void)hipHostFree(e->h_status);
   fr(e->dbg_trace);
   fr(e->krp_ws);
   fr(e->d_jk_norms);
@@ -1244,7 +1273,7 @@ int cals_hip_run(cals_hip_engine *e, cals_hip_report *rep) {
     iter++;
     int rc = admit(e, nullptr);
     if (rc) return rc;
-    if ((rc = sweep_once(e, true))) return rc;
+    if ((rc = sweep_once(e, true, true))) return rc;
     if ((rc = fetch_status(e))) return rc;
     if (e->prm.line_search)
       for (auto t : e->registry) {

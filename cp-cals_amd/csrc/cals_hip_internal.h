@@ -179,6 +179,15 @@ struct FinishArgs {
 };
 hipError_t finish_launch(const FinishArgs &a, hipStream_t st);   // cals.cpp:336-354
 
+// per-sweep status read-back of cals_hip_run: one packed record per in-flight model (registry order)
+struct StatusRec {
+  int flags, pad;      // pad = slot (header record: flags = line-search "changed" flag)
+  long long iters;     // header record: number of records that follow
+  double err, fit, old_fit;
+};
+hipError_t pack_status_launch(const int *slots, int n, const ModelTable &mt, const int *changed,
+                              StatusRec *out, hipStream_t st);
+
 // set-up kernels
 // X: src_dtype elements (as uploaded), Xp: dst_dtype elements
 hipError_t permute_pad_launch(const void *X, int src_dtype, int n_modes, const int *dims, int m_mode,

@@ -18,6 +18,7 @@
 // [col, col+r) of a CALS_RMAX x buffer matrix (ld = CALS_RMAX).
 #include "cals_hip_internal.h"
 
+#include <algorithm>
 #include <cfloat>
 #include <type_traits>
 
@@ -660,6 +661,38 @@ __global__ void finish_kernel(const FinishArgs a) {
     a.mt.flags[slot] |= 4;
   else
     a.mt.iters[slot] = it + 1;
+}
+
+// per-sweep status of the in-flight models, packed in registry order for ONE device-to-host copy:
+// out[0] = {changed flag of the line search, -, -, -, -}; out[1 + k] = record of slots[k]
+__global__ void pack_status_kernel(const int *slots, int n, ModelTable mt, const int *changed,
+                                   StatusRec *out) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k == 0) {
+    StatusRec h;
+    h.flags = changed ? *changed : 0;
+    h.pad = 0;
+    h.iters = n;
+    h.err = h.fit = h.old_fit = 0.0;
+    out[0] = h;
+  }
+  if (k >= n) return;
+  const int slot = slots[k];
+  StatusRec r;
+  r.flags = mt.flags[slot];
+  r.pad = slot;
+  r.iters = mt.iters[slot];
+  r.err = mt.err[slot];
+  r.fit = mt.fit[slot];
+  r.old_fit = mt.old_fit[slot];
+  out[1 + k] = r;
+}
+
+hipError_t pack_status_launch(const int *slots, int n, const ModelTable &mt, const int *changed,
+                              StatusRec *out, hipStream_t st) {
+  hipLaunchKernelGGL(pack_status_kernel, dim3((std::max(n, 1) + 127) / 128), dim3(128), 0, st, slots, n,
+                     mt, changed, out);
+  return hipGetLastError();
 }
 
 hipError_t finish_launch(const FinishArgs &a, hipStream_t st) {

@@ -116,8 +116,6 @@ static __device__ __forceinline__ void run(const TtmArgs &a, const int m0, const
   const long long s_end = S * (tm + 1) / a.T;
   const long long n_units = (s_end - s_begin) * nAb;
 
-  const int col = nb * CALS_BN + wave * 16 + lcol;
-  const bool cvalid = col < a.R;
 
   acc_t tacc[MT], gacc[MT];
 #pragma unroll
