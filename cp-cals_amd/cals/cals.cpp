@@ -331,6 +331,116 @@ JKReport jk_cp_cals(const Tensor &X, vector<Ktensor> &kt_vector, CalsParams &cal
   return rep;
 }
 
+namespace {
+CalsParams to_cals_params(const AlsParams &ap, dim_t buffer_size) {
+  CalsParams p;
+  p.update_method = ap.update_method;
+  p.max_iterations = ap.max_iterations;
+  p.tol = ap.tol;
+  p.cuda = ap.cuda;
+  p.buffer_size = buffer_size;
+  p.line_search = ap.line_search;
+  p.line_search_interval = ap.line_search_interval;
+  p.line_search_step = ap.line_search_step;
+  p.line_search_method = ap.line_search_method;
+  p.force_max_iter = ap.force_max_iter;
+  p.device = ap.device;
+  return p;
+}
+}  // namespace
+
+// cp_omp_als (include/als.h:218, src/als.cpp:340-360): every model fitted independently by ALS.  The
+// reference spreads the models over OpenMP threads; on the device "all of them at once" IS the
+// concurrent engine, whose per-model results equal cp_als (tests/cals/test_cals.cpp:60-86).
+vector<AlsReport> cp_omp_als(const Tensor &X, vector<Ktensor> &ktensor_v, AlsParams &params) {
+  Timer total;
+  total.start();
+  dim_t cols = 0;
+  for (auto &k : ktensor_v) cols += k.get_components();
+  CalsParams p = to_cals_params(params, std::max<dim_t>(cols, 1));
+  KtensorQueue q;
+  for (auto &k : ktensor_v) q.emplace(k);
+  CalsReport r = cp_cals(X, q, p);
+  total.stop();
+  vector<AlsReport> reports(ktensor_v.size());
+  for (size_t i = 0; i < ktensor_v.size(); i++) {
+    reports[i].iter = ktensor_v[i].get_iters();
+    reports[i].X_norm = r.X_norm;
+    reports[i].total_time = total.get_time();
+  }
+  return reports;
+}
+
+// jk_cp_als / jk_cp_omp_als (include/als.h:203,220, src/als.cpp:362-500): the jackknife comparator --
+// every replica is a plain model of the SUB-SAMPLED tensor (mode-0 slice i removed).  Replicas of
+// all input models that share a removed slice share one engine run on that sub-tensor.
+JKReport jk_cp_omp_als(const Tensor &X, vector<Ktensor> &kt_vector, AlsParams &als_params) {
+  const auto modes = X.get_modes();
+  if (modes.size() != 3) throw std::runtime_error("jk_cp_als: 3-way tensors only (src/als.cpp:364-365)");
+  const dim_t I0 = modes[0], rest = modes[1] * modes[2];
+  vector<Ktensor> ktensors(kt_vector);
+  for (auto &k : ktensors) {
+    k.denormalize();
+    k.normalize();
+  }
+  auto jk_modes(modes);
+  jk_modes[0] -= 1;
+  vector<vector<Ktensor>> jk_input(ktensors.size());
+  for (auto &k : jk_input) k.resize(I0);
+  double pre_time = 0.0, als_time = 0.0;
+  for (dim_t i_jk = 0; i_jk < I0; i_jk++) {
+    Timer pre, run;
+    pre.start();
+    Tensor X_jk(jk_modes);
+    for (dim_t jj = 0; jj < rest; jj++)
+      for (dim_t ii = 0; ii < I0; ii++) {
+        if (ii == i_jk) continue;
+        X_jk[(ii < i_jk ? ii : ii - 1) + (I0 - 1) * jj] = X[ii + I0 * jj];
+      }
+    dim_t cols = 0;
+    for (size_t i_kt = 0; i_kt < ktensors.size(); i_kt++) {
+      const Ktensor &src = ktensors[i_kt];
+      Ktensor kt_jk(src.get_components(), jk_modes);
+      kt_jk.get_lambda() = src.get_lambda();
+      for (dim_t f = 0; f < 3; f++) {
+        const Matrix &fs = src.get_factor(f);
+        Matrix &fd = kt_jk.get_factor(f);
+        for (dim_t jj = 0; jj < fs.get_cols(); jj++)
+          for (dim_t ii = 0; ii < fs.get_rows(); ii++) {
+            if (f == 0 && ii == i_jk) continue;
+            fd((f == 0 && ii > i_jk) ? ii - 1 : ii, jj) = fs(ii, jj);
+          }
+      }
+      cols += src.get_components();
+      jk_input[i_kt][i_jk] = std::move(kt_jk);
+    }
+    pre.stop();
+    run.start();
+    CalsParams p = to_cals_params(als_params, std::max<dim_t>(cols, 1));
+    KtensorQueue q;
+    for (size_t i_kt = 0; i_kt < ktensors.size(); i_kt++) q.emplace(jk_input[i_kt][i_jk]);
+    cp_cals(X_jk, q, p);
+    run.stop();
+    pre_time += pre.get_time();
+    als_time += run.get_time();
+  }
+  for (auto &k : jk_input)
+    for (auto &m : k) {
+      m.denormalize();
+      m.normalize();
+    }
+  for (size_t i = 0; i < ktensors.size(); i++) utils::jk_permutation_adjustment(ktensors[i], jk_input[i]);
+  JKReport rep;
+  rep.jk_time.pre_als_time = pre_time;
+  rep.jk_time.als_time = als_time;
+  rep.results = std::move(jk_input);
+  return rep;
+}
+
+JKReport jk_cp_als(const Tensor &X, vector<Ktensor> &kt_vector, AlsParams &als_params) {
+  return jk_cp_omp_als(X, kt_vector, als_params);
+}
+
 }  // namespace cals
 
 // C entry point of the assignment solver (tests bind it with ctypes)

@@ -382,6 +382,8 @@ struct AlsReport {
   double total_time{0.0};
 };
 AlsReport cp_als(const Tensor &X, Ktensor &ktensor, AlsParams &als_params);
+// include/als.h:218: the reference's OpenMP-over-models ALS; here all models run concurrently on the device
+vector<AlsReport> cp_omp_als(const Tensor &X, vector<Ktensor> &ktensor, AlsParams &params);
 
 // include/als.h:22-25, 168-170
 struct JKTime {
@@ -411,6 +413,9 @@ inline int get_threads() { return 1; }
 // Jackknife driver (src/cals.cpp:397-446): for every model of kt_vector, modes[0] jackknife
 // replicas fitted in ONE cp_cals call, then re-normalised and column-matched to the original.
 JKReport jk_cp_cals(const Tensor &X, vector<Ktensor> &kt_vector, CalsParams &cals_params);
+// include/als.h:203,220: jackknife by ALS on the sub-sampled tensors (the comparator of jk_cp_cals)
+JKReport jk_cp_als(const Tensor &X, vector<Ktensor> &kt_vector, AlsParams &als_params);
+JKReport jk_cp_omp_als(const Tensor &X, vector<Ktensor> &kt_vector, AlsParams &als_params);
 
 // Fits every Ktensor of the queue to X with concurrent ALS on the GPU and overwrites it with the
 // result (factors, lambda, error, fit, iters); the queue is empty on return (include/cals.h:183-196).

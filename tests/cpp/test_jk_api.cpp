@@ -1,6 +1,7 @@
 // cals::jk_cp_cals (C++ layer -> C ABI -> HIP engine) against the oracle's jk_cp_cals: the
 // reference's CalsJackknifingTests.FunctionCorrectness (tests/cals/test_cals.cpp:299-362) with the
 // oracle in place of jk_cp_als.  Test infrastructure: links oracle/liboracle.so.
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <vector>
@@ -126,5 +127,49 @@ int main() {
     }
   printf("jk_cp_cals C++ API: %zu models x %zu replicas, worst ||T_gpu - T_oracle|| / factor diff = %.3e\n",
          (size_t)n_ktensors, (size_t)modes[0], worst);
-  return (worst <= 1e-9) ? 0 : 1;
+
+  // The reference's own criterion (tests/cals/test_cals.cpp:343-361): jk_cp_cals == jk_cp_als, the
+  // jackknife by plain ALS on the sub-sampled tensors (here: the same engine on X without slice i).
+  double worst_als = 0.0;
+  try {
+    cals::JKReport rep2 = cals::jk_cp_als(T, refs, ap);
+    for (dim_t k = 0; k < n_ktensors; k++)
+      for (dim_t i = 0; i < modes[0]; i++) {
+        cals::Tensor a = rep.results[k][i].to_regular().to_tensor();
+        cals::Tensor b = rep2.results[k][i].to_tensor();
+        double d = 0.0;
+        for (dim_t e = 0; e < a.get_n_elements(); e++) d += (a[e] - b[e]) * (a[e] - b[e]);
+        d = std::sqrt(d);
+        if (!(d <= worst_als)) worst_als = d;
+      }
+  } catch (const std::exception &e) {
+    fprintf(stderr, "jk_cp_als threw: %s\n", e.what());
+    return 2;
+  }
+  printf("jk_cp_cals vs jk_cp_als (sub-sampled tensors): worst ||T_cals - T_als|| = %.3e\n", worst_als);
+
+  // cp_omp_als == cp_als model by model (include/als.h:218)
+  double worst_omp = 0.0;
+  {
+    std::vector<cals::Ktensor> a_in, b_in;
+    for (dim_t k = 0; k < 4; k++) {
+      a_in.emplace_back((dim_t)(2 + k), modes);
+      a_in.back().fill([]() { return next_pm1(); });
+    }
+    b_in = a_in;
+    auto reps = cals::cp_omp_als(T, a_in, ap);
+    for (size_t k = 0; k < b_in.size(); k++) {
+      cals::AlsReport r1 = cals::cp_als(T, b_in[k], ap);
+      if (r1.iter != reps[k].iter) worst_omp = 1.0;
+      for (int n = 0; n < 3; n++) {
+        const auto &fa = a_in[k].get_factor(n), &fb = b_in[k].get_factor(n);
+        for (dim_t e = 0; e < fa.get_n_elements(); e++) {
+          const double x = std::fabs(fa.get_data()[e] - fb.get_data()[e]);
+          if (!(x <= worst_omp)) worst_omp = x;
+        }
+      }
+    }
+  }
+  printf("cp_omp_als vs cp_als: worst factor entry difference = %.3e\n", worst_omp);
+  return (worst <= 1e-9 && worst_als <= 1e-8 && worst_omp <= 1e-10) ? 0 : 1;
 }
