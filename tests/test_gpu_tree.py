@@ -35,6 +35,8 @@ def plan(request):
     ([17, 330, 9], [5, 20, 7]),
     ([40, 30, 20], [20] * 21),               # R = 420: four column blocks
     ([161, 23, 50], [32, 1, 20]),            # 11 m-tiles: M blocks of 6 and 5 tiles (k_big = 1)
+    ([600, 7, 5], [3, 20]),                  # 38 m-tiles: 4 M blocks; contraction rows > 512 (generic kernel)
+    ([6, 1100, 3], [4, 9]),                  # the same for the middle mode (fp32: > 1024 rows)
 ])
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
 def test_tree_mttkrp_every_mode_vs_oracle(cc, oracle, inputs, plan, modes, ranks, dtype):
