@@ -520,6 +520,8 @@ int sweep_once(cals_hip_engine *e, bool evict_enabled, bool defer_changed = fals
     HIPCHK(ls_snapshot_launch(la, e->stream));
     prof_end(e, pk);
   }
+  int rank_max = 1;  // sizes the update kernel's LDS panel
+  for (auto t : e->registry) rank_max = std::max(rank_max, (int)e->models[t].rank);
   for (int n = 0; n < e->n_modes; n++) {
     Geo g{0, 0};
     const bool by_contract = e->tree.on && e->tree.t_second == n;
@@ -549,11 +551,12 @@ int sweep_once(cals_hip_engine *e, bool evict_enabled, bool defer_changed = fals
     u.is_last = (n == e->n_modes - 1);
     u.X_norm = e->X_norm;
     u.jk_norms = e->d_jk_norms;
+    u.dbg_trace = e->dbg_trace ? e->dbg_trace + 16 * 2048 - 64 : nullptr;  // last 64 entries of the trace
     const int pk = prof_begin(e, 1, 0);
     if (!by_contract)
       HIPCHK(reduce_partials_launch(e->partial, g.T, e->lay[n].ldPart, (int)e->modes[n], (int)R,
                                     e->factor[n], e->dtype, e->stream));
-    HIPCHK(update_launch(u, CALS_RMAX, e->stream));
+    HIPCHK(update_launch(u, rank_max, e->stream));
     prof_end(e, pk);
   }
   if (e->prm.line_search) {

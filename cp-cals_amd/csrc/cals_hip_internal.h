@@ -126,6 +126,8 @@ struct UpdateArgs {
   int is_last;
   double X_norm;
   const double *jk_norms;
+  unsigned long long *dbg_trace;  // CALS_DIAG builds: phase stamps of the first rank-20 model (mode 0)
+  int xld;             // set by update_launch: > 0 = leading dimension of the LDS-resident panel
 };
 hipError_t update_launch(const UpdateArgs &a, int rmax_needed, hipStream_t st);
 // deterministic reduction of the MTTKRP split partials into the multi-factor of the mode

@@ -20,11 +20,22 @@
 
 #include <algorithm>
 #include <cfloat>
+#include <cstdlib>
 #include <type_traits>
 
 namespace calship {
 
 typedef double v4d __attribute__((ext_vector_type(4)));
+
+#ifdef CALS_DIAG
+#define UPD_STAMP(k)                                                                          \
+  do {                                                                                        \
+    if (a.dbg_trace && a.mode == 0 && r == 20 && blockIdx.x < 24 && threadIdx.x == 0)         \
+      a.dbg_trace[k] = __builtin_amdgcn_s_memtime();                                          \
+  } while (0)
+#else
+#define UPD_STAMP(k) do { } while (0)
+#endif
 
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
@@ -69,8 +80,8 @@ __device__ __forceinline__ void gramian_wave(const T *panel, int rows, long long
 }
 
 // Partial Gramian of rows [row0, row1) on the matrix cores (see gramian_wave); accumulators out.
-template <typename T>
-__device__ __forceinline__ void gramian_rows(const T *panel, int row0, int row1, int rows,
+template <typename PTR>
+__device__ __forceinline__ void gramian_rows(PTR panel, int row0, int row1, int rows,
                                              long long ld, int r, int lane, v4d &a00, v4d &a01,
                                              v4d &a11) {
   const int krow = lane >> 4, lcol = lane & 15;
@@ -127,6 +138,7 @@ __device__ __attribute__((noinline)) void update_body(const UpdateArgs &a, int s
   const int I = a.I;
   double *Hs = sh.Hs;
 
+  UPD_STAMP(0);
   // H = hadamard of the other modes' Gramians (hadamard_but_one)
   for (int e = tid; e < r * r; e += UPD_THREADS) {
     const int i = e % r, j = e / r;
@@ -137,6 +149,7 @@ __device__ __attribute__((noinline)) void update_body(const UpdateArgs &a, int s
   }
   __syncthreads();
 
+  UPD_STAMP(1);
   // dpotrf('L') restated as unblocked dpotf2 (lane = row; every wave computes, wave 0 writes).
   // info != 0: stop, keep going with whatever is in H, as the reference does
   // (update.cpp:183-185 only logs).
@@ -171,6 +184,7 @@ __device__ __attribute__((noinline)) void update_body(const UpdateArgs &a, int s
   if (tid == 0) a.mt.potrf_info[slot] = info;
   __syncthreads();
   const double *dinv = sh.dinv;
+  UPD_STAMP(2);
 
   // storage type T (double | float); all arithmetic below is fp64
   T *fac = static_cast<T *>(a.factor) + (long long)I * col;
@@ -244,6 +258,7 @@ __device__ __attribute__((noinline)) void update_body(const UpdateArgs &a, int s
     }
   }
 
+  UPD_STAMP(3);
   // column scales: wave butterflies (independent per column, so they pipeline), then the four
   // waves are combined in fixed order by thread c
 #pragma unroll
@@ -276,6 +291,7 @@ __device__ __attribute__((noinline)) void update_body(const UpdateArgs &a, int s
   t3 = wave_sum(t3);
   if (lane == 0) sh.redt[wave] = t3;
   __syncthreads();
+  UPD_STAMP(4);
   if (tid < r) {
     double lam;
     if (first) {
@@ -303,6 +319,7 @@ __device__ __attribute__((noinline)) void update_body(const UpdateArgs &a, int s
   t3 = sh.redt[0] + sh.redt[1] + sh.redt[2] + sh.redt[3];
   const double *lams = sh.lams;
 
+  UPD_STAMP(5);
   // pass 2: cblas_dscal by 1/lambda (skipped for lambda == 0); each thread rescales its own rows
   for (int i = tid; i < I; i += UPD_THREADS) {
 #pragma unroll
@@ -315,6 +332,7 @@ __device__ __attribute__((noinline)) void update_body(const UpdateArgs &a, int s
   }
   __syncthreads();
 
+  UPD_STAMP(6);
   // update_gramian: rows split over the four waves, partial tiles combined in fixed order
   {
     v4d a00 = {0.0, 0.0, 0.0, 0.0}, a01 = {0.0, 0.0, 0.0, 0.0}, a11 = {0.0, 0.0, 0.0, 0.0};
@@ -353,6 +371,251 @@ __device__ __attribute__((noinline)) void update_body(const UpdateArgs &a, int s
     }
   }
 
+  UPD_STAMP(7);
+  if (a.is_last) {
+    __syncthreads();
+    double t2 = 0.0;
+    for (int e = tid; e < r * r; e += UPD_THREADS) {
+      const int i = e % r, j = e / r;
+      double h = 1.0;
+      for (int m = 0; m < a.n_modes; ++m) h *= a.gram[m][i + CALS_RMAX * (long long)(col + j)];
+      t2 += lams[i] * lams[j] * h;
+    }
+    t2 = wave_sum(t2);
+    __syncthreads();
+    if (lane == 0) sh.redt[wave] = t2;
+    __syncthreads();
+    if (tid == 0) {
+      t2 = sh.redt[0] + sh.redt[1] + sh.redt[2] + sh.redt[3];
+      const int jm = a.mt.jk_mode[slot];
+      const double xn = (jm >= 0) ? a.jk_norms[a.mt.jk_fiber[slot]] : a.X_norm;
+      const double e2 = fmax(xn * xn + t2 - 2.0 * t3, 0.0);
+      const double err = sqrt(e2);
+      a.mt.err[slot] = err;
+      const double of = a.mt.fit[slot];
+      a.mt.old_fit[slot] = of;
+      a.mt.fit[slot] = 1.0 - fabs(err) / a.X_norm;
+    }
+  }
+}
+
+// The same update with the model's factor panel kept in LDS between the phases (used when
+// I x r_max elements fit next to UpdShared; the body above, which goes through global memory between
+// its passes, remains for taller modes).  Measured on a rank-20 model at C2/C3 (tools/update_trace.py)
+// the first version spent 36 % of its 45-57 us in the Cholesky (every thread recomputing the pivots,
+// two block barriers per column) and 28 % in per-thread column statistics reduced by 20 butterflies
+// per wave.  Here: the Cholesky runs on ONE wave without block barriers (LDS operations of a wave
+// execute in order); the solved rows go to LDS; each wave reduces r/4 columns reading LDS; the
+// scaling pass and the Gramian read LDS instead of reloading the panel from HBM.
+// Arithmetic: Cholesky, solves, scaling and Gramian are operation-for-operation those of the body
+// above; the column norms of a model's first sweep are summed in a different (fixed) order.
+extern __shared__ __attribute__((aligned(16))) unsigned char upd_dyn[];
+
+template <int RMAX, typename T>
+__device__ __attribute__((noinline)) void update_body_lds(const UpdateArgs &a, int slot, int r,
+                                                          UpdShared &sh) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int col = a.mt.col[slot];
+  const long long iters = a.mt.iters[slot];
+  const int jkf = (a.mt.jk_mode[slot] == a.mode) ? a.mt.jk_fiber[slot] : -1;
+  const int I = a.I;
+  const int xld = a.xld;
+  double *Hs = sh.Hs;
+  T *xs = reinterpret_cast<T *>(upd_dyn);  // I x r panel, ld = xld (storage type, like the factor)
+
+  UPD_STAMP(0);
+  // H = hadamard of the other modes' Gramians (hadamard_but_one)
+  for (int e = tid; e < r * r; e += UPD_THREADS) {
+    const int i = e % r, j = e / r;
+    double h = 1.0;
+    for (int m = 0; m < a.n_modes; ++m)
+      if (m != a.mode) h *= a.gram[m][i + CALS_RMAX * (long long)(col + j)];
+    Hs[i + RMAX * j] = h;
+  }
+  __syncthreads();
+  UPD_STAMP(1);
+
+  // dpotrf('L') restated as unblocked dpotf2 on wave 0 (lane = row).  info != 0: stop, keep going
+  // with whatever is in H, as the reference does (update.cpp:183-185 only logs).
+  if (wave == 0) {
+    int info = 0;
+    for (int j = 0; j < r; ++j) {
+      const bool below = lane > j && lane < r;
+      double ajj = Hs[j + RMAX * j];
+      double sv = below ? Hs[lane + RMAX * j] : 0.0;
+      for (int k = 0; k < j; ++k) {
+        const double ljk = Hs[j + RMAX * k];
+        ajj -= ljk * ljk;
+        if (below) sv -= Hs[lane + RMAX * k] * ljk;
+      }
+      if (!(ajj > 0.0)) {
+        if (lane == 0) Hs[j + RMAX * j] = ajj;
+        info = j + 1;
+        break;
+      }
+      ajj = sqrt(ajj);
+      if (lane == j)
+        Hs[j + RMAX * j] = ajj;
+      else if (below)
+        Hs[lane + RMAX * j] = sv / ajj;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    }
+    if (lane < r) sh.dinv[lane] = 1.0 / Hs[lane + RMAX * lane];
+    if (lane == 0) a.mt.potrf_info[slot] = info;
+  }
+  __syncthreads();
+  const double *dinv = sh.dinv;
+  UPD_STAMP(2);
+
+  T *fac = static_cast<T *>(a.factor) + (long long)I * col;
+  const bool first = (iters == 1);
+  double t3 = 0.0;
+
+  // rows: G row -> two triangular solves -> unnormalised factor row, into the LDS panel
+  for (int i = tid; i < I; i += UPD_THREADS) {
+    double x[RMAX], g[RMAX];
+    asm volatile("" ::: "memory");  // keep L in LDS (see update_body)
+#pragma unroll
+    for (int c = 0; c < RMAX; ++c) {
+      x[c] = (c < r) ? (double)fac[i + (long long)I * c] : 0.0;
+      g[c] = x[c];
+    }
+#pragma unroll
+    for (int k = 0; k < RMAX; ++k) {
+      if (k < r) {
+        x[k] = dinv[k] * x[k];
+#pragma unroll
+        for (int j = k + 1; j < RMAX; ++j)
+          if (j < r) x[j] -= Hs[j + RMAX * k] * x[k];
+      }
+    }
+#pragma unroll
+    for (int j = RMAX - 1; j >= 0; --j) {
+      if (j < r) {
+#pragma unroll
+        for (int k = j + 1; k < RMAX; ++k)
+          if (k < r) x[j] -= Hs[k + RMAX * j] * x[k];
+        x[j] = dinv[j] * x[j];
+      }
+    }
+    if (i == jkf) {
+#pragma unroll
+      for (int c = 0; c < RMAX; ++c) x[c] *= 0.0;
+    }
+#pragma unroll
+    for (int c = 0; c < RMAX; ++c) {
+      if (c < r) {
+        xs[i + xld * c] = (T)x[c];
+        t3 += x[c] * g[c];
+      }
+    }
+  }
+  t3 = wave_sum(t3);
+  if (lane == 0) sh.redt[wave] = t3;
+  __syncthreads();
+  t3 = sh.redt[0] + sh.redt[1] + sh.redt[2] + sh.redt[3];
+  UPD_STAMP(3);
+
+  // column scales (Ktensor::normalize(mode, iteration), src/ktensor.cpp:66-83): wave w owns columns
+  // w, w + 4, ...; first sweep of a model: 2-norm; later: the entry of largest magnitude, first
+  // index on ties (cblas_idamax), with its sign
+  for (int c = wave; c < r; c += UPD_WAVES) {
+    const T *cp = xs + xld * c;
+    double lam;
+    if (first) {
+      double ss = 0.0;
+      for (int i = lane; i < I; i += 64) {
+        const double x = (double)cp[i];
+        ss += x * x;
+      }
+      lam = sqrt(wave_sum(ss));
+    } else {
+      double m = -1.0, v = 0.0;
+      int ix = 0x7fffffff;
+      for (int i = lane; i < I; i += 64) {
+        const double x = (double)cp[i];
+        const double ax = fabs(x);
+        if (ax > m) {
+          m = ax;
+          v = x;
+          ix = i;
+        }
+      }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        const double m2 = __shfl_xor(m, off);
+        const double v2 = __shfl_xor(v, off);
+        const int i2 = __shfl_xor(ix, off);
+        const bool take = (m2 > m) || (m2 == m && i2 < ix);
+        m = take ? m2 : m;
+        v = take ? v2 : v;
+        ix = take ? i2 : ix;
+      }
+      lam = v;
+    }
+    if (lane == 0) {
+      sh.lams[c] = lam;
+      a.lambda[col + c] = lam;
+    }
+  }
+  __syncthreads();
+  const double *lams = sh.lams;
+  UPD_STAMP(5);
+
+  // cblas_dscal by 1/lambda (skipped for lambda == 0): the normalised factor goes to HBM once and
+  // stays in LDS (rounded to the storage type) for the Gramian
+  for (int c = 0; c < r; ++c) {
+    const double lam = lams[c];
+    const double inv = (lam != 0.0) ? 1.0 / lam : 1.0;
+    for (int i = tid; i < I; i += UPD_THREADS) {
+      T v = xs[i + xld * c];
+      if (lam != 0.0) v = (T)(inv * (double)v);
+      fac[i + (long long)I * c] = v;
+      xs[i + xld * c] = v;
+    }
+  }
+  __syncthreads();
+  UPD_STAMP(6);
+
+  // update_gramian: rows split over the four waves, partial tiles combined in fixed order
+  {
+    v4d a00 = {0.0, 0.0, 0.0, 0.0}, a01 = {0.0, 0.0, 0.0, 0.0}, a11 = {0.0, 0.0, 0.0, 0.0};
+    const int chunk = ((I + UPD_WAVES - 1) / UPD_WAVES + 7) / 8 * 8;
+    const int row0 = wave * chunk, row1 = min(I, row0 + chunk);
+    gramian_rows((const T *)xs, row0, row1, I, (long long)xld, r, lane, a00, a01, a11);
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      sh.gp[wave][0][lane * 4 + reg] = a00[reg];
+      sh.gp[wave][1][lane * 4 + reg] = a01[reg];
+      sh.gp[wave][2][lane * 4 + reg] = a11[reg];
+    }
+  }
+  __syncthreads();
+  {
+    double *g = a.gram[a.mode] + CALS_RMAX * (long long)col;
+    const int tile = tid >> 6;
+    if (tile < 3) {
+      const int krow = lane >> 4, lcol = lane & 15;
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int e = lane * 4 + reg;
+        const double v = ((sh.gp[0][tile][e] + sh.gp[1][tile][e]) + sh.gp[2][tile][e]) + sh.gp[3][tile][e];
+        const int row = krow + 4 * reg;
+        if (tile == 0) {
+          if (row < r && lcol < r) g[row + CALS_RMAX * lcol] = v;
+        } else if (tile == 1) {
+          if (row < r && 16 + lcol < r) {
+            g[row + CALS_RMAX * (16 + lcol)] = v;
+            g[(16 + lcol) + CALS_RMAX * row] = v;
+          }
+        } else {
+          if (16 + row < r && 16 + lcol < r) g[(16 + row) + CALS_RMAX * (16 + lcol)] = v;
+        }
+      }
+    }
+  }
+  UPD_STAMP(7);
+
   if (a.is_last) {
     __syncthreads();
     double t2 = 0.0;
@@ -385,6 +648,23 @@ __global__ void __launch_bounds__(UPD_THREADS, 1) update_kernel(const UpdateArgs
   __shared__ UpdShared sh;
   const int slot = a.slots[blockIdx.x];
   const int r = a.mt.rank[slot];
+  if (a.xld > 0) {  // the panel fits in LDS next to UpdShared (update_launch decides)
+    if (r <= 4)
+      update_body_lds<4, T>(a, slot, r, sh);
+    else if (r <= 8)
+      update_body_lds<8, T>(a, slot, r, sh);
+    else if (r <= 12)
+      update_body_lds<12, T>(a, slot, r, sh);
+    else if (r <= 16)
+      update_body_lds<16, T>(a, slot, r, sh);
+    else if (r <= 20)
+      update_body_lds<20, T>(a, slot, r, sh);
+    else if (r <= 24)
+      update_body_lds<24, T>(a, slot, r, sh);
+    else
+      update_body_lds<32, T>(a, slot, r, sh);
+    return;
+  }
   if (r <= 4)
     update_body<4, T>(a, slot, r, sh);
   else if (r <= 8)
@@ -465,12 +745,41 @@ hipError_t init_slots_launch(const int *desc, int n, const ModelTable &mt, hipSt
   return hipGetLastError();
 }
 
-hipError_t update_launch(const UpdateArgs &a, int, hipStream_t st) {
-  if (a.n_slots <= 0) return hipSuccess;
-  if (a.dtype == CALS_F32)
-    hipLaunchKernelGGL(update_kernel<float>, dim3(a.n_slots), dim3(UPD_THREADS), 0, st, a);
-  else
-    hipLaunchKernelGGL(update_kernel<double>, dim3(a.n_slots), dim3(UPD_THREADS), 0, st, a);
+// rmax_needed: largest rank among the models in flight (sizes the LDS panel)
+hipError_t update_launch(const UpdateArgs &a_in, int rmax_needed, hipStream_t st) {
+  if (a_in.n_slots <= 0) return hipSuccess;
+  UpdateArgs a = a_in;
+  const size_t es = (a.dtype == CALS_F32) ? sizeof(float) : sizeof(double);
+  const int xld = a.I | 1;  // odd leading dimension: the Gramian's 4 x 16 operand reads spread over banks
+  const int rmax = std::min(std::max(rmax_needed, 1), CALS_RMAX);
+  size_t dyn = (size_t)xld * (size_t)rmax * es;
+  dyn = (dyn + 15) / 16 * 16;
+  const size_t budget = (size_t)160 * 1024 - sizeof(UpdShared) - 1024;
+  static const bool no_lds = getenv("CALS_UPDATE_NO_LDS") != nullptr;  // A/B switch
+  if (dyn <= budget && !no_lds) {
+    a.xld = xld;
+  } else {
+    a.xld = 0;
+    dyn = 0;
+  }
+  static size_t attr_f64 = 0, attr_f32 = 0;
+  if (a.dtype == CALS_F32) {
+    if (dyn > attr_f32) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&update_kernel<float>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)budget);
+      if (e != hipSuccess) return e;
+      attr_f32 = budget;
+    }
+    hipLaunchKernelGGL(update_kernel<float>, dim3(a.n_slots), dim3(UPD_THREADS), dyn, st, a);
+  } else {
+    if (dyn > attr_f64) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&update_kernel<double>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)budget);
+      if (e != hipSuccess) return e;
+      attr_f64 = budget;
+    }
+    hipLaunchKernelGGL(update_kernel<double>, dim3(a.n_slots), dim3(UPD_THREADS), dyn, st, a);
+  }
   return hipGetLastError();
 }
 
