@@ -443,10 +443,26 @@ __device__ __attribute__((noinline)) void update_body_lds(const UpdateArgs &a, i
       const bool below = lane > j && lane < r;
       double ajj = Hs[j + RMAX * j];
       double sv = below ? Hs[lane + RMAX * j] : 0.0;
-      for (int k = 0; k < j; ++k) {
+      const int lrow = below ? lane : j;  // lanes outside the column read row j again (unused)
+      int k = 0;
+      for (; k + 4 <= j; k += 4) {  // four load pairs in flight; the subtractions stay in k order
+        const double l0 = Hs[j + RMAX * k], l1 = Hs[j + RMAX * (k + 1)];
+        const double l2 = Hs[j + RMAX * (k + 2)], l3 = Hs[j + RMAX * (k + 3)];
+        const double m0 = Hs[lrow + RMAX * k], m1 = Hs[lrow + RMAX * (k + 1)];
+        const double m2 = Hs[lrow + RMAX * (k + 2)], m3 = Hs[lrow + RMAX * (k + 3)];
+        ajj -= l0 * l0;
+        ajj -= l1 * l1;
+        ajj -= l2 * l2;
+        ajj -= l3 * l3;
+        sv -= m0 * l0;
+        sv -= m1 * l1;
+        sv -= m2 * l2;
+        sv -= m3 * l3;
+      }
+      for (; k < j; ++k) {
         const double ljk = Hs[j + RMAX * k];
         ajj -= ljk * ljk;
-        if (below) sv -= Hs[lane + RMAX * k] * ljk;
+        sv -= Hs[lrow + RMAX * k] * ljk;
       }
       if (!(ajj > 0.0)) {
         if (lane == 0) Hs[j + RMAX * j] = ajj;
@@ -519,43 +535,64 @@ __device__ __attribute__((noinline)) void update_body_lds(const UpdateArgs &a, i
   // column scales (Ktensor::normalize(mode, iteration), src/ktensor.cpp:66-83): wave w owns columns
   // w, w + 4, ...; first sweep of a model: 2-norm; later: the entry of largest magnitude, first
   // index on ties (cblas_idamax), with its sign
-  for (int c = wave; c < r; c += UPD_WAVES) {
-    const T *cp = xs + xld * c;
-    double lam;
-    if (first) {
-      double ss = 0.0;
-      for (int i = lane; i < I; i += 64) {
-        const double x = (double)cp[i];
-        ss += x * x;
-      }
-      lam = sqrt(wave_sum(ss));
-    } else {
-      double m = -1.0, v = 0.0;
-      int ix = 0x7fffffff;
-      for (int i = lane; i < I; i += 64) {
-        const double x = (double)cp[i];
-        const double ax = fabs(x);
-        if (ax > m) {
-          m = ax;
-          v = x;
-          ix = i;
+  {
+    constexpr int NC = (RMAX + UPD_WAVES - 1) / UPD_WAVES;  // columns wave, wave + 4, ... of this wave
+    double m[NC], v[NC];
+    int ix[NC];
+#pragma unroll
+    for (int q = 0; q < NC; ++q) {
+      m[q] = first ? 0.0 : -1.0;
+      v[q] = 0.0;
+      ix[q] = 0x7fffffff;
+    }
+    for (int i = lane; i < I; i += 64) {
+#pragma unroll
+      for (int q = 0; q < NC; ++q) {
+        const int c = wave + UPD_WAVES * q;
+        if (c < r) {
+          const double x = (double)xs[i + xld * c];
+          if (first) {
+            m[q] += x * x;
+          } else {
+            const double ax = fabs(x);
+            if (ax > m[q]) {
+              m[q] = ax;
+              v[q] = x;
+              ix[q] = i;
+            }
+          }
         }
       }
+    }
+    if (first) {
 #pragma unroll
-      for (int off = 32; off > 0; off >>= 1) {
-        const double m2 = __shfl_xor(m, off);
-        const double v2 = __shfl_xor(v, off);
-        const int i2 = __shfl_xor(ix, off);
-        const bool take = (m2 > m) || (m2 == m && i2 < ix);
-        m = take ? m2 : m;
-        v = take ? v2 : v;
-        ix = take ? i2 : ix;
-      }
-      lam = v;
+      for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+        for (int q = 0; q < NC; ++q) m[q] += __shfl_xor(m[q], off);
+    } else {
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+        for (int q = 0; q < NC; ++q) {
+          const double m2 = __shfl_xor(m[q], off);
+          const double v2 = __shfl_xor(v[q], off);
+          const int i2 = __shfl_xor(ix[q], off);
+          const bool take = (m2 > m[q]) || (m2 == m[q] && i2 < ix[q]);
+          m[q] = take ? m2 : m[q];
+          v[q] = take ? v2 : v[q];
+          ix[q] = take ? i2 : ix[q];
+        }
     }
     if (lane == 0) {
-      sh.lams[c] = lam;
-      a.lambda[col + c] = lam;
+#pragma unroll
+      for (int q = 0; q < NC; ++q) {
+        const int c = wave + UPD_WAVES * q;
+        if (c < r) {
+          const double lam = first ? sqrt(m[q]) : v[q];
+          sh.lams[c] = lam;
+          a.lambda[col + c] = lam;
+        }
+      }
     }
   }
   __syncthreads();
@@ -564,14 +601,16 @@ __device__ __attribute__((noinline)) void update_body_lds(const UpdateArgs &a, i
 
   // cblas_dscal by 1/lambda (skipped for lambda == 0): the normalised factor goes to HBM once and
   // stays in LDS (rounded to the storage type) for the Gramian
-  for (int c = 0; c < r; ++c) {
-    const double lam = lams[c];
-    const double inv = (lam != 0.0) ? 1.0 / lam : 1.0;
-    for (int i = tid; i < I; i += UPD_THREADS) {
-      T v = xs[i + xld * c];
-      if (lam != 0.0) v = (T)(inv * (double)v);
-      fac[i + (long long)I * c] = v;
-      xs[i + xld * c] = v;
+  for (int i = tid; i < I; i += UPD_THREADS) {
+#pragma unroll
+    for (int c = 0; c < RMAX; ++c) {
+      if (c < r) {
+        const double lam = lams[c];
+        T v = xs[i + xld * c];
+        if (lam != 0.0) v = (T)((1.0 / lam) * (double)v);
+        fac[i + (long long)I * c] = v;
+        xs[i + xld * c] = v;
+      }
     }
   }
   __syncthreads();
