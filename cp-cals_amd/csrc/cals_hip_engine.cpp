@@ -410,6 +410,8 @@ Geo tree_geometry(const cals_hip_engine *e, int first, int64_t R) {
   long long T = e->n_cu / std::max(1, g.NB);
   if (T < 1) T = 1;
   if (T > e->modes[second]) T = e->modes[second];
+  static const int forced_t = getenv("CALS_TTM_TEAMS") ? atoi(getenv("CALS_TTM_TEAMS")) : 0;  // experiments
+  if (forced_t > 0) T = std::min<long long>(forced_t, e->modes[second]);
   g.T = (int)T;
   return g;
 }
