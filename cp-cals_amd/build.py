@@ -22,6 +22,12 @@ def build(force=False, verbose=False):
     objs = []
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
     os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
+    # objects built with other -D switches (CALS_DIAG, ring depths) must not survive into this build
+    variant = " ".join("%s=%s" % (k, os.environ[k]) for k in ("CALS_V3_RING", "CALS_DIAG", "CALS_TTM_RING")
+                       if os.environ.get(k)) or "production"
+    stamp = os.path.join(HERE, "build", "variant.txt")
+    if not os.path.exists(stamp) or open(stamp).read() != variant:
+        force = True
     for s in SOURCES:
         src = os.path.join(CSRC, s)
         obj = os.path.join(HERE, "build", os.path.splitext(s)[0] + ".o")
@@ -36,6 +42,8 @@ def build(force=False, verbose=False):
                 print(" ".join(cmd))
             subprocess.check_call(cmd)
         objs.append(obj)
+    with open(stamp, "w") as f:
+        f.write(variant)
     if force or _newer(LIB, objs):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
         if verbose:
