@@ -308,16 +308,35 @@ static __device__ __forceinline__ void run(const TtmArgs &a, const int m0, const
     bool pend = false;       // LATE: flush of the previous unit deferred behind this unit's barrier
     long long s_pend = 0;
     T q_pend[C::NQ] = {};
-    for (long long iu = 0; iu < n_units; ++iu) {
-      const int buf_n = (buf == 2) ? 0 : buf + 1;
-      const int buf_nn = (buf_n == 2) ? 0 : buf_n + 1;
-      const unsigned bufb = lds0 + (unsigned)(buf * C::BUF * C::ES);
-      const unsigned base = bufb + lane_off;
+    // DMA sources of the unit two stages ahead and the LDS addresses of the next stage are carried
+    // across iterations and advanced INSIDE the MFMA stream (right behind the last DMA issue), by
+    // additions: between a wave's last MFMA of a stage and the barrier nothing but the DMA wait is
+    // left.  (While waves 4-7 walk from their last MFMA to the barrier, waves 0-3 are already parked
+    // at it: that tail is dead time for the SIMD.)
+    const T *src_slab = Xp + (long long)a.Mp * (16 * ab_2) + slab_stride_s * s_2;
+    const T *p_slab = Pt_nb + (long long)(16 * ab_2) * CALS_BN;
+    const T *q_row = Qm + s_2;
+    const long long src_wrap = slab_stride_s - (long long)a.Mp * 16 * nAb;  // + one a-block step = next s
+    unsigned bufb = lds0 + (unsigned)(buf * C::BUF * C::ES), base = bufb + lane_off;
+    unsigned bufb_n = bufb, base_n = base;
+    int buf_nn = (buf + 2) % 3;
+    auto advance = [&]() {  // called once per stage, mid-stream
+      ab_2 = ab_2 + 1;
+      src_slab += (long long)a.Mp * 16;
+      p_slab += 16 * CALS_BN;
+      if (ab_2 >= nAb) {
+        ab_2 = 0;
+        s_2++;
+        src_slab += src_wrap;
+        p_slab = Pt_nb;
+        q_row += 1;
+      }
+      const int b1 = (buf == 2) ? 0 : buf + 1;
+      bufb_n = lds0 + (unsigned)(b1 * C::BUF * C::ES);
+      base_n = bufb_n + lane_off;
+    };
+    for (int iu = 0; iu < n_units; ++iu) {
       const bool fetch = iu + 2 < n_units;
-      // CALS_DIAG, dbg 4 (timing only, results garbage): always the same slab => every X DMA hits the L2
-      const T *src_slab = DIAG(a.dbg & 4) ? Xp : Xp + (long long)a.Mp * (16 * ab_2) + slab_stride_s * s_2;
-      const T *p_slab = Pt_nb + (long long)(16 * ab_2) * CALS_BN;
-      const T *q_row = Qm + s_2;
       T *dst = lds + buf_nn * C::BUF;
 
       if constexpr (LATE) {
@@ -369,6 +388,7 @@ static __device__ __forceinline__ void run(const TtmArgs &a, const int m0, const
               if constexpr (LATE && Is < C::HH) {
                 if (fetch) issue_at.template operator()<Is>(src_slab, p_slab, q_row, dst);
               }
+              if constexpr (LATE && Is == (C::NDMA < C::H - 1 ? C::NDMA : C::H - 1)) advance();
             }(),
             ...);
       }(std::make_integer_sequence<int, C::H>{});
@@ -399,6 +419,7 @@ static __device__ __forceinline__ void run(const TtmArgs &a, const int m0, const
               if constexpr (!LATE && Is < C::HH) {
                 if (fetch) issue_at.template operator()<Is>(src_slab, p_slab, q_row, dst);
               }
+              if constexpr (!LATE && Is == (C::NDMA < C::N - C::H - 1 ? C::NDMA : C::N - C::H - 1)) advance();
             }(),
             ...);
       }(std::make_integer_sequence<int, C::N - C::H>{});
@@ -413,13 +434,12 @@ static __device__ __forceinline__ void run(const TtmArgs &a, const int m0, const
           flush(s_c, qcur);
         }
       }
-      buf = buf_n;
-      ab_c = ab_1;
-      s_c = s_1;
-      ab_1 = ab_2;
-      s_1 = s_2;
-      ab_2 = ab_2 + 1;
-      if (ab_2 >= nAb) { ab_2 = 0; s_2++; }
+      buf = (buf == 2) ? 0 : buf + 1;
+      buf_nn = (buf_nn == 2) ? 0 : buf_nn + 1;
+      bufb = bufb_n;
+      base = base_n;
+      ab_c = ab_c + 1;
+      if (ab_c >= nAb) { ab_c = 0; s_c++; }
     }
     if constexpr (LATE) {
       if (pend) flush(s_pend, q_pend);
