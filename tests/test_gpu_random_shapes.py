@@ -1,0 +1,76 @@
+"""Randomised shapes through every MTTKRP plan and path, both storage types: catches geometry edge
+cases (one-tile modes, S smaller than the team, a single a-block, ragged column blocks, rank 32)."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import make_models, rel
+
+pytestmark = pytest.mark.gpu
+
+
+def _cases(n, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n):
+        kind = rng.integers(0, 4)
+        if kind == 0:
+            modes = [int(v) for v in rng.integers(2, 9, size=3)]
+        elif kind == 1:
+            modes = [int(v) for v in rng.integers(2, 70, size=3)]
+        elif kind == 2:
+            modes = [int(rng.integers(150, 400)), int(rng.integers(2, 6)), int(rng.integers(2, 30))]
+            rng.shuffle(modes)
+            modes = [int(v) for v in modes]
+        else:
+            modes = [int(v) for v in rng.integers(14, 20, size=3)]  # around the 16-row tile edge
+        n_models = int(rng.integers(1, 12))
+        # keep the Hadamard of the Gramians well conditioned: rank well below the product of any two modes
+        pr = sorted(modes)
+        rmax = max(1, min(32, (pr[0] * pr[1]) // 4))
+        ranks = [int(v) for v in rng.integers(1, rmax + 1, size=n_models)]
+        out.append((modes, ranks, ["0", "A", "B", "M"][int(rng.integers(0, 4))],
+                    ["f64", "f32"][int(rng.integers(0, 2))], int(rng.integers(0, 1 << 30))))
+    return out
+
+
+@pytest.mark.parametrize("modes,ranks,plan,dtype,seed", _cases(80, 20260101))
+def test_random_shape_mttkrp_and_sweeps(cc, oracle, inputs, modes, ranks, plan, dtype, seed):
+    old = os.environ.get("CALS_HIP_TREE")
+    os.environ["CALS_HIP_TREE"] = plan
+    try:
+        X = inputs.tensor(modes, seed % 1000)
+        base = make_models(inputs, modes, ranks, seed=1 + seed % 997)
+        e = cc.Engine(modes, sum(ranks), dtype=dtype)
+        e.set_tensor(X)
+        e.set_params(cc.default_params(max_iterations=4, force_max_iter=1, line_search=seed & 1,
+                                       line_search_interval=2))
+        gm = [cc.Model([f.copy() for f in fs], lam.copy()) for fs, lam, _ in base]
+        for m in gm:
+            e.enqueue(m)
+        e.admit()
+        facs = [np.asfortranarray(np.hstack([fs[n] for fs, _, _ in base])) for n in range(3)]
+        tol = 1e-12 if dtype == "f64" else 3e-5
+        pairs = {"0": [], "A": [0], "B": [1], "M": [0, 1, 2]}[plan]
+        for n in range(3):
+            want = oracle.mttkrp(X, modes, facs, n, oracle.MTTKRP)
+            scale = max(np.linalg.norm(want), 1e-300)
+            for path in ["plain"] + (["first"] if n in pairs else []) + (["second"] if (n + 2) % 3 in pairs else []):
+                assert np.linalg.norm(e.debug_mttkrp(n, path) - want) / scale < tol, (n, path)
+        e.run()
+        e.close()
+        om = [oracle.Model(fs, lam) for fs, lam, _ in base]
+        oracle.cp_cals(X, modes, om, oracle.default_params(
+            max_iterations=4, force_max_iter=1, line_search=seed & 1, line_search_interval=2,
+            mttkrp_method=oracle.MTTKRP, buffer_size=sum(ranks)))
+        rtol = 1e-8 if dtype == "f64" else 2e-3
+        for a, b in zip(gm, om):
+            assert a.iters == b.iters
+            for fa, fb in zip(a.factors, b.factors):
+                assert rel(fa, fb) < rtol
+    finally:
+        if old is None:
+            os.environ.pop("CALS_HIP_TREE", None)
+        else:
+            os.environ["CALS_HIP_TREE"] = old
