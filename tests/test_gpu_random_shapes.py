@@ -74,3 +74,51 @@ def test_random_shape_mttkrp_and_sweeps(cc, oracle, inputs, modes, ranks, plan, 
             os.environ.pop("CALS_HIP_TREE", None)
         else:
             os.environ["CALS_HIP_TREE"] = old
+
+
+def _life_cases(n, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n):
+        modes = [int(v) for v in rng.integers(8, 25, size=3)]
+        n_models = int(rng.integers(8, 40))
+        ranks = [int(v) for v in rng.integers(1, 9, size=n_models)]
+        buffer = int(rng.integers(max(ranks), max(max(ranks) + 1, sum(ranks) // 2)))
+        out.append((modes, ranks, buffer, ["0", "A", "B", "M"][int(rng.integers(0, 4))],
+                    int(rng.integers(0, 2)), float(10.0 ** -rng.integers(3, 6)), int(rng.integers(0, 1 << 30))))
+    return out
+
+
+@pytest.mark.parametrize("modes,ranks,buffer,plan,ls,tol,seed", _life_cases(24, 777))
+def test_random_queue_life_cycle(cc, oracle, inputs, modes, ranks, buffer, plan, ls, tol, seed):
+    """Queue longer than the buffer, tolerance-driven eviction, compress, optional line search: the
+    same admission order, per-model iteration counts and fitted tensors as the oracle, under every
+    MTTKRP plan (T shared across sweeps must be dropped whenever the column layout changes)."""
+    from helpers import reconstruct
+    old = os.environ.get("CALS_HIP_TREE")
+    os.environ["CALS_HIP_TREE"] = plan
+    try:
+        X = inputs.low_rank_tensor(modes, 5, seed=seed % 1000)[0] + 0.05 * inputs.tensor(modes, seed % 977)
+        base = make_models(inputs, modes, ranks, seed=1 + seed % 991)
+        kw = dict(max_iterations=30, tol=tol, line_search=ls, line_search_interval=3)
+        e = cc.Engine(modes, buffer)
+        e.set_tensor(X)
+        e.set_params(cc.default_params(**kw))
+        gm = [cc.Model([f.copy() for f in fs], lam.copy()) for fs, lam, _ in base]
+        for m in gm:
+            e.enqueue(m)
+        rep = e.run()
+        e.close()
+        om = [oracle.Model(fs, lam) for fs, lam, _ in base]
+        ro = oracle.cp_cals(X, modes, om, oracle.default_params(mttkrp_method=oracle.MTTKRP, buffer_size=buffer, **kw))
+        assert (rep.iter, rep.n_ktensors, rep.ktensor_comp_sum) == (ro.iter, ro.n_ktensors, ro.ktensor_comp_sum)
+        assert (rep.ls_performed, rep.ls_failed) == (ro.ls_performed, ro.ls_failed)
+        for a, b in zip(gm, om):
+            assert a.iters == b.iters
+            d = np.linalg.norm(reconstruct(a.factors, a.lam, modes) - reconstruct(b.factors, b.lam, modes))
+            assert d <= 1e-8 * max(1.0, np.linalg.norm(X))
+    finally:
+        if old is None:
+            os.environ.pop("CALS_HIP_TREE", None)
+        else:
+            os.environ["CALS_HIP_TREE"] = old
