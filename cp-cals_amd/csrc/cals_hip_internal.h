@@ -6,7 +6,8 @@
 #include <stdint.h>
 
 #define CALS_MAX_MODES 8
-#define CALS_RMAX 32          // rank limit of the batched per-model kernels; Gramian store ld
+#define CALS_RMAX 64          // rank limit per model; leading dimension of the Gramian stores
+#define CALS_RFAST 32         // ranks up to this run the register-resident update bodies
 #define CALS_BN 128           // columns of the multi-factor per MTTKRP workgroup
 
 namespace calship {

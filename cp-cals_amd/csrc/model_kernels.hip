@@ -43,13 +43,33 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
-// Gamma = P^T P for the I x r panel (ld) with r <= 32, on the f64 matrix cores: each k-step covers 4
+template <typename PTR>
+__device__ __forceinline__ v4d gramian_tile(PTR panel, int row0, int row1, long long ld, int r,
+                                            int lane, int bi, int bj);
+
+// Gamma = P^T P for the I x r panel (ld) on the f64 matrix cores (r <= 32 in one pass): each k-step covers 4
 // rows; lane (lcol, krow) supplies P[i0+krow, lcol] as both the A and the B operand.
 // Written to g (ld = CALS_RMAX).  Must be called by a whole wave with EXEC all ones.
 template <typename T>
 __device__ __forceinline__ void gramian_wave(const T *panel, int rows, long long ld, int r,
                                              double *g, int lane) {
   const int krow = lane >> 4, lcol = lane & 15;
+  if (r > CALS_RFAST) {  // ranks 33..64: one pass over the panel per tile pair
+    const int nt = (r + 15) >> 4;
+    for (int bi = 0; bi < nt; ++bi)
+      for (int bj = bi; bj < nt; ++bj) {
+        const v4d t = gramian_tile(panel, 0, rows, ld, r, lane, bi, bj);
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const int row = 16 * bi + krow + 4 * reg, cc = 16 * bj + lcol;
+          if (row < r && cc < r) {
+            g[row + CALS_RMAX * cc] = t[reg];
+            g[cc + CALS_RMAX * row] = t[reg];
+          }
+        }
+      }
+    return;
+  }
   const bool two = r > 16;
   v4d a00 = {0.0, 0.0, 0.0, 0.0}, a01 = {0.0, 0.0, 0.0, 0.0}, a11 = {0.0, 0.0, 0.0, 0.0};
   const bool c0ok = lcol < r, c1ok = (16 + lcol) < r;
@@ -77,6 +97,23 @@ __device__ __forceinline__ void gramian_wave(const T *panel, int rows, long long
       if (16 + row < r && 16 + lcol < r) g[(16 + row) + CALS_RMAX * (16 + lcol)] = a11[reg];
     }
   }
+}
+
+// One 16 x 16 tile (bi, bj) of P^T P over rows [row0, row1): the general form used for ranks > 32.
+template <typename PTR>
+__device__ __forceinline__ v4d gramian_tile(PTR panel, int row0, int row1, long long ld, int r,
+                                            int lane, int bi, int bj) {
+  const int krow = lane >> 4, lcol = lane & 15;
+  const bool ciok = (16 * bi + lcol) < r, cjok = (16 * bj + lcol) < r;
+  v4d acc = {0.0, 0.0, 0.0, 0.0};
+  for (int i0 = row0; i0 < row1; i0 += 4) {
+    const int i = i0 + krow;
+    const bool rok = i < row1;
+    const double pi = (rok && ciok) ? (double)panel[i + ld * (16 * bi + lcol)] : 0.0;
+    const double pj = (bi == bj) ? pi : ((rok && cjok) ? (double)panel[i + ld * (16 * bj + lcol)] : 0.0);
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pi, pj, acc, 0, 0, 0);
+  }
+  return acc;
 }
 
 // Partial Gramian of rows [row0, row1) on the matrix cores (see gramian_wave); accumulators out.
@@ -117,11 +154,11 @@ __device__ __forceinline__ void gramian_rows(PTR panel, int row0, int row1, int 
 #define UPD_WAVES 4
 
 struct UpdShared {
-  double Hs[CALS_RMAX * CALS_RMAX];
+  double Hs[CALS_RFAST * CALS_RFAST];
   double dinv[CALS_RMAX];
   double lams[CALS_RMAX];
-  double red[UPD_WAVES][CALS_RMAX][2];
-  int redi[UPD_WAVES][CALS_RMAX];
+  double red[UPD_WAVES][CALS_RFAST][2];
+  int redi[UPD_WAVES][CALS_RFAST];
   double redt[UPD_WAVES];
   double gp[UPD_WAVES][3][256];
 };
@@ -682,11 +719,220 @@ __device__ __attribute__((noinline)) void update_body_lds(const UpdateArgs &a, i
   }
 }
 
+// Ranks 33..64: the same update with H (64 x 64) in dynamic LDS and the factor panel going through
+// HBM between the phases (a thread still keeps its row in registers for the two solves).  The
+// error term sum_c A_unnorm[i,c] G[i,c] is accumulated as |L^-1 g_i|^2 (algebraically the same;
+// G is not kept next to the 64-entry row).  Slower than the bodies above by design: it only has to
+// be right.
+template <typename T>
+__device__ __attribute__((noinline)) void update_body_big(const UpdateArgs &a, int slot, int r,
+                                                          UpdShared &sh) {
+  constexpr int RM = CALS_RMAX;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int col = a.mt.col[slot];
+  const long long iters = a.mt.iters[slot];
+  const int jkf = (a.mt.jk_mode[slot] == a.mode) ? a.mt.jk_fiber[slot] : -1;
+  const int I = a.I;
+  double *Hb = reinterpret_cast<double *>(upd_dyn);  // RM x RM
+  double *gpb = Hb + RM * RM;                        // [UPD_WAVES][256] partial Gramian tiles
+
+  for (int e = tid; e < r * r; e += UPD_THREADS) {
+    const int i = e % r, j = e / r;
+    double h = 1.0;
+    for (int m = 0; m < a.n_modes; ++m)
+      if (m != a.mode) h *= a.gram[m][i + CALS_RMAX * (long long)(col + j)];
+    Hb[i + RM * j] = h;
+  }
+  __syncthreads();
+  if (wave == 0) {  // dpotf2 order, lane = row (r <= 64 = one wave)
+    int info = 0;
+    for (int j = 0; j < r; ++j) {
+      const bool below = lane > j && lane < r;
+      const int lrow = below ? lane : j;
+      double ajj = Hb[j + RM * j];
+      double sv = below ? Hb[lane + RM * j] : 0.0;
+      for (int k = 0; k < j; ++k) {
+        const double ljk = Hb[j + RM * k];
+        ajj -= ljk * ljk;
+        sv -= Hb[lrow + RM * k] * ljk;
+      }
+      if (!(ajj > 0.0)) {
+        if (lane == 0) Hb[j + RM * j] = ajj;
+        info = j + 1;
+        break;
+      }
+      ajj = sqrt(ajj);
+      if (lane == j)
+        Hb[j + RM * j] = ajj;
+      else if (below)
+        Hb[lane + RM * j] = sv / ajj;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    }
+    if (lane < r) sh.dinv[lane] = 1.0 / Hb[lane + RM * lane];
+    if (lane == 0) a.mt.potrf_info[slot] = info;
+  }
+  __syncthreads();
+  const double *dinv = sh.dinv;
+
+  T *fac = static_cast<T *>(a.factor) + (long long)I * col;
+  const bool first = (iters == 1);
+  double t3 = 0.0;
+  for (int i = tid; i < I; i += UPD_THREADS) {
+    double x[RM];
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int c = 0; c < RM; ++c) x[c] = (c < r) ? (double)fac[i + (long long)I * c] : 0.0;
+#pragma unroll
+    for (int k = 0; k < RM; ++k) {
+      if (k < r) {
+        x[k] = dinv[k] * x[k];
+#pragma unroll
+        for (int j = k + 1; j < RM; ++j)
+          if (j < r) x[j] -= Hb[j + RM * k] * x[k];
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < RM; ++c)
+      if (c < r) t3 += x[c] * x[c];
+#pragma unroll
+    for (int j = RM - 1; j >= 0; --j) {
+      if (j < r) {
+#pragma unroll
+        for (int k = j + 1; k < RM; ++k)
+          if (k < r) x[j] -= Hb[k + RM * j] * x[k];
+        x[j] = dinv[j] * x[j];
+      }
+    }
+    if (i == jkf) {
+      // the reference zeroes the row after the solve (ktensor.h:316-325); its share of term3 goes too
+#pragma unroll
+      for (int c = 0; c < RM; ++c) x[c] *= 0.0;
+    }
+#pragma unroll
+    for (int c = 0; c < RM; ++c)
+      if (c < r) fac[i + (long long)I * c] = (T)x[c];
+  }
+  t3 = wave_sum(t3);
+  if (lane == 0) sh.redt[wave] = t3;
+  __threadfence_block();
+  __syncthreads();
+  t3 = sh.redt[0] + sh.redt[1] + sh.redt[2] + sh.redt[3];
+
+  for (int c = wave; c < r; c += UPD_WAVES) {  // column scales (Ktensor::normalize(mode, iteration))
+    const T *cp = fac + (long long)I * c;
+    double lam;
+    if (first) {
+      double ss = 0.0;
+      for (int i = lane; i < I; i += 64) {
+        const double x = (double)cp[i];
+        ss += x * x;
+      }
+      lam = sqrt(wave_sum(ss));
+    } else {
+      double m = -1.0, v = 0.0;
+      int ix = 0x7fffffff;
+      for (int i = lane; i < I; i += 64) {
+        const double x = (double)cp[i];
+        const double ax = fabs(x);
+        if (ax > m) {
+          m = ax;
+          v = x;
+          ix = i;
+        }
+      }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        const double m2 = __shfl_xor(m, off);
+        const double v2 = __shfl_xor(v, off);
+        const int i2 = __shfl_xor(ix, off);
+        const bool take = (m2 > m) || (m2 == m && i2 < ix);
+        m = take ? m2 : m;
+        v = take ? v2 : v;
+        ix = take ? i2 : ix;
+      }
+      lam = v;
+    }
+    if (lane == 0) {
+      sh.lams[c] = lam;
+      a.lambda[col + c] = lam;
+    }
+  }
+  __syncthreads();
+  const double *lams = sh.lams;
+  for (int c = 0; c < r; ++c) {
+    const double lam = lams[c];
+    if (lam != 0.0)
+      for (int i = tid; i < I; i += UPD_THREADS)
+        fac[i + (long long)I * c] = (T)((1.0 / lam) * (double)fac[i + (long long)I * c]);
+  }
+  __threadfence_block();
+  __syncthreads();
+
+  {  // update_gramian, one 16 x 16 tile pair at a time, rows split over the waves
+    double *g = a.gram[a.mode] + CALS_RMAX * (long long)col;
+    const int nt = (r + 15) >> 4;
+    const int chunk = ((I + UPD_WAVES - 1) / UPD_WAVES + 3) / 4 * 4;
+    const int row0 = wave * chunk, row1 = min(I, row0 + chunk);
+    const int krow = lane >> 4, lcol = lane & 15;
+    for (int bi = 0; bi < nt; ++bi)
+      for (int bj = bi; bj < nt; ++bj) {
+        const v4d t = gramian_tile((const T *)fac, row0, row1, (long long)I, r, lane, bi, bj);
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) gpb[wave * 256 + lane * 4 + reg] = t[reg];
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+          for (int reg = 0; reg < 4; ++reg) {
+            const int e = lane * 4 + reg;
+            const double v = ((gpb[e] + gpb[256 + e]) + gpb[512 + e]) + gpb[768 + e];
+            const int row = 16 * bi + krow + 4 * reg, cc = 16 * bj + lcol;
+            if (row < r && cc < r) {
+              g[row + CALS_RMAX * cc] = v;
+              g[cc + CALS_RMAX * row] = v;
+            }
+          }
+        }
+        __syncthreads();
+      }
+  }
+
+  if (a.is_last) {
+    __threadfence_block();
+    __syncthreads();
+    double t2 = 0.0;
+    for (int e = tid; e < r * r; e += UPD_THREADS) {
+      const int i = e % r, j = e / r;
+      double h = 1.0;
+      for (int m = 0; m < a.n_modes; ++m) h *= a.gram[m][i + CALS_RMAX * (long long)(col + j)];
+      t2 += lams[i] * lams[j] * h;
+    }
+    t2 = wave_sum(t2);
+    __syncthreads();
+    if (lane == 0) sh.redt[wave] = t2;
+    __syncthreads();
+    if (tid == 0) {
+      t2 = sh.redt[0] + sh.redt[1] + sh.redt[2] + sh.redt[3];
+      const int jm = a.mt.jk_mode[slot];
+      const double xn = (jm >= 0) ? a.jk_norms[a.mt.jk_fiber[slot]] : a.X_norm;
+      const double e2 = fmax(xn * xn + t2 - 2.0 * t3, 0.0);
+      const double err = sqrt(e2);
+      a.mt.err[slot] = err;
+      const double of = a.mt.fit[slot];
+      a.mt.old_fit[slot] = of;
+      a.mt.fit[slot] = 1.0 - fabs(err) / a.X_norm;
+    }
+  }
+}
+
 template <typename T>
 __global__ void __launch_bounds__(UPD_THREADS, 1) update_kernel(const UpdateArgs a) {
   __shared__ UpdShared sh;
   const int slot = a.slots[blockIdx.x];
   const int r = a.mt.rank[slot];
+  if (r > CALS_RFAST) {
+    update_body_big<T>(a, slot, r, sh);
+    return;
+  }
   if (a.xld > 0) {  // the panel fits in LDS next to UpdShared (update_launch decides)
     if (r <= 4)
       update_body_lds<4, T>(a, slot, r, sh);
@@ -790,17 +1036,20 @@ hipError_t update_launch(const UpdateArgs &a_in, int rmax_needed, hipStream_t st
   UpdateArgs a = a_in;
   const size_t es = (a.dtype == CALS_F32) ? sizeof(float) : sizeof(double);
   const int xld = a.I | 1;  // odd leading dimension: the Gramian's 4 x 16 operand reads spread over banks
-  const int rmax = std::min(std::max(rmax_needed, 1), CALS_RMAX);
+  const int rmax = std::min(std::max(rmax_needed, 1), CALS_RFAST);  // panel of the fast bodies
   size_t dyn = (size_t)xld * (size_t)rmax * es;
   dyn = (dyn + 15) / 16 * 16;
   const size_t budget = (size_t)160 * 1024 - sizeof(UpdShared) - 1024;
   static const bool no_lds = getenv("CALS_UPDATE_NO_LDS") != nullptr;  // A/B switch
+  // ranks 33..64 in flight: update_body_big needs H (64 x 64) + 4 partial tiles in dynamic LDS
+  const size_t big = (rmax_needed > CALS_RFAST) ? (size_t)(CALS_RMAX * CALS_RMAX + UPD_WAVES * 256) * sizeof(double) : 0;
   if (dyn <= budget && !no_lds) {
     a.xld = xld;
   } else {
     a.xld = 0;
     dyn = 0;
   }
+  if (big > dyn) dyn = big;  // the two uses of the dynamic region never coexist in one workgroup
   static size_t attr_f64 = 0, attr_f32 = 0;
   if (a.dtype == CALS_F32) {
     if (dyn > attr_f32) {

@@ -20,7 +20,7 @@ extern "C" {
 #endif
 
 #define CALS_HIP_MAX_MODES 8
-#define CALS_HIP_MAX_RANK 32 /* per-model rank limit of the batched update kernels (round 1) */
+#define CALS_HIP_MAX_RANK 64 /* per-model rank limit (ranks above 32 take a slower update body) */
 
 /* status codes */
 enum {

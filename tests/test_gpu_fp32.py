@@ -77,6 +77,7 @@ def test_f32_host_tensor_upload_is_equivalent(cc, inputs):
     ([50, 40, 30], None, 0),
     ([50, 40, 30], None, 1),
     ([6, 5, 4, 3], [3, 4, 5], 0),
+    ([40, 36, 33], [40, 7, 64], 0),            # ranks above 32
 ])
 def test_f32_ten_sweeps_vs_fp64_oracle(cc, oracle, inputs, modes, ranks, ls):
     if ranks is None:

@@ -85,10 +85,11 @@ def test_tensor_norms(cc, oracle, inputs):
     e.close()
 
 
-@pytest.mark.parametrize("ranks", [[1], [2], [5], [20], [32], [1, 20, 7, 32, 13]])
+@pytest.mark.parametrize("ranks", [[1], [2], [5], [20], [32], [1, 20, 7, 32, 13], [33], [48], [64], [3, 40, 64, 17]])
 def test_single_sweep_state_vs_oracle(cc, oracle, inputs, ranks):
     """One sweep: factors, lambda, Gramians, error, fit of every model (update kernel unit test
-    through the public path; ranks cover every register class of the kernel, 32 = the limit)."""
+    through the public path; ranks cover every register class of the kernel and, above 32, the
+    big-rank body; 64 = the limit)."""
     modes = [40, 36, 33]
     X = inputs.tensor(modes, 6)
     prm = cc.default_params(max_iterations=100, force_max_iter=1)
@@ -167,6 +168,7 @@ def _assert_models_match(gm, om, xnorm2, tol=TOL_RUN):
     ([13, 12, 11], list(range(1, 13)) * 3, 30),
     ([6, 5, 4, 3], [3, 4, 5], 10),
     ([50, 40, 30], None, 10),
+    ([40, 36, 33], [33, 64, 48, 5, 20], 10),   # ranks above 32: the big-rank update body
 ])
 def test_forced_iterations_vs_oracle(cc, oracle, inputs, modes, ranks, iters):
     if ranks is None:
@@ -218,9 +220,9 @@ def test_queue_eviction_compress_vs_oracle(cc, oracle, inputs, ls):
 
 def test_rejects_bad_input_loudly(cc, inputs):
     e = cc.Engine([8, 8, 8], 16)
-    fs = [np.zeros((8, 40), order="F")] * 3
+    fs = [np.zeros((8, 65), order="F")] * 3
     with pytest.raises(cc.CalsHipError):
-        e.enqueue(cc.Model(fs, np.ones(40)))         # rank > CALS_HIP_MAX_RANK / buffer
+        e.enqueue(cc.Model(fs, np.ones(65)))         # rank > CALS_HIP_MAX_RANK / buffer
     with pytest.raises(cc.CalsHipError):
         e.sweep(1)                                     # no tensor yet
     with pytest.raises(cc.CalsHipError):

@@ -28,7 +28,7 @@ def _cases(n, seed):
         n_models = int(rng.integers(1, 12))
         # keep the Hadamard of the Gramians well conditioned: rank well below the product of any two modes
         pr = sorted(modes)
-        rmax = max(1, min(32, (pr[0] * pr[1]) // 4))
+        rmax = max(1, min(64 if rng.integers(0, 4) == 0 else 32, (pr[0] * pr[1]) // 4))
         ranks = [int(v) for v in rng.integers(1, rmax + 1, size=n_models)]
         out.append((modes, ranks, ["0", "A", "B", "M"][int(rng.integers(0, 4))],
                     ["f64", "f32"][int(rng.integers(0, 2))], int(rng.integers(0, 1 << 30))))
