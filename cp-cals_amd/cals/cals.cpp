@@ -443,6 +443,18 @@ JKReport jk_cp_als(const Tensor &X, vector<Ktensor> &kt_vector, AlsParams &als_p
 
 }  // namespace cals
 
+extern "C" int solve_rectangular_linear_sum_assignment(intptr_t nr, intptr_t nc, double *input_cost,
+                                                        bool maximize, int64_t *a, int64_t *b) {
+  if (nr != nc || nr < 1 || !input_cost || !a || !b) return -1;
+  const int n = (int)nr;
+  std::vector<double> cm((size_t)n * n);  // row-major in, column-major for the solver
+  for (int i = 0; i < n; i++)
+    for (int j = 0; j < n; j++) cm[(size_t)i + (size_t)n * j] = input_cost[(size_t)i * n + j];
+  const int rc = cals::solve_linear_sum_assignment(n, cm.data(), maximize, b);
+  for (int i = 0; i < n; i++) a[i] = i;
+  return rc;
+}
+
 // C entry point of the assignment solver (tests bind it with ctypes)
 extern "C" int cals_lsap_solve(int n, const double *cost_colmajor, int maximize, int64_t *col_of_row) {
   return cals::solve_linear_sum_assignment(n, cost_colmajor, maximize != 0, col_of_row);

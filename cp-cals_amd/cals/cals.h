@@ -32,6 +32,14 @@ enum UPDATE_METHOD { UNCONSTRAINED = 0, NNLS, LENGTH };
 }
 namespace mttkrp {  // include/utils/mttkrp.h:23-31 (kept for source compatibility; one fused kernel here)
 enum MTTKRP_METHOD { MTTKRP = 0, TWOSTEP0, TWOSTEP1, AUTO, LENGTH };
+// include/utils/mttkrp.h:15-19, 100-101.  The lookup tables choose among the reference's CPU/CUDA
+// MTTKRP variants per (mode, rank, threads); the device engine picks its own plan (cals_hip_tree), so
+// the table is accepted and ignored and read_lookup_table returns an empty one.
+struct MttkrpLut {
+  std::vector<std::vector<int>> lut_v{};
+  std::vector<int> keys_v{};
+};
+inline MttkrpLut read_lookup_table(std::vector<dim_t> const &, int, bool = false, bool = false) { return {}; }
 }
 namespace ls {  // include/utils/line_search.h:8
 enum LS_METHOD { NO_ERROR_CHECKING = 0, ERROR_CHECKING_SERIAL, ERROR_CHECKING_PARALLEL, LENGTH };
@@ -198,6 +206,14 @@ class Ktensor {
   vector<double> &get_lambda() noexcept { return lambda; }
   const vector<double> &get_lambda() const noexcept { return lambda; }
   void set_iters(dim_t v) noexcept { iters = v; }
+  // include/ktensor.h:161-170
+  void set_factor(int index, const double *src) noexcept {
+    Matrix &t = get_factor((dim_t)index);
+    std::copy(src, src + t.get_n_elements(), t.get_data());
+  }
+  void set_lambda(double const *src) noexcept {
+    for (size_t i = 0; i < lambda.size(); i++) lambda[i] = src[i];
+  }
   void set_approximation_error(double v) noexcept { approx_error = v; }
   void set_fit(double f, double of) noexcept { fit = f; old_fit = of; }
   double calculate_new_fit(double X_norm) noexcept {  // include/ktensor.h:178-183
@@ -328,6 +344,7 @@ struct CalsReport {
 struct CalsParams {
   update::UPDATE_METHOD update_method{update::UNCONSTRAINED};
   mttkrp::MTTKRP_METHOD mttkrp_method{mttkrp::AUTO};
+  mttkrp::MttkrpLut mttkrp_lut{};  // accepted and ignored (see read_lookup_table)
   dim_t max_iterations{200};
   double tol{1e-7};
   bool cuda{true};
@@ -363,6 +380,7 @@ class Timer {
 struct AlsParams {
   update::UPDATE_METHOD update_method{update::UNCONSTRAINED};
   mttkrp::MTTKRP_METHOD mttkrp_method{mttkrp::AUTO};
+  mttkrp::MttkrpLut mttkrp_lut{};
   dim_t max_iterations{200};
   double tol{1e-7};
   bool cuda{true};
@@ -406,6 +424,12 @@ void jk_permutation_adjustment(Ktensor &ktensor, vector<Ktensor> &jk_ktensor_v);
 // rectangular_lsap, extern/rectangular_lsap): col_of_row[i] = column assigned to row i.
 // Own implementation (Hungarian / Kuhn-Munkres with potentials), returns 0 on success.
 int solve_linear_sum_assignment(int n, const double *cost_colmajor, bool maximize, int64_t *col_of_row);
+}  // namespace cals
+// extern/rectangular_lsap/rectangular_lsap.h:44 (the MEX front-ends call it directly): row-major nr x nc
+// cost, a = row indices, b = assigned columns.  Square problems only (all the reference's call sites).
+extern "C" int solve_rectangular_linear_sum_assignment(intptr_t nr, intptr_t nc, double *input_cost,
+                                                        bool maximize, int64_t *a, int64_t *b);
+namespace cals {
 
 inline void set_threads(int) {}   // include/cals_blas.h:184-186: host BLAS threads; no meaning here
 inline int get_threads() { return 1; }

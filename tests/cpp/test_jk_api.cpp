@@ -171,5 +171,21 @@ int main() {
     }
   }
   printf("cp_omp_als vs cp_als: worst factor entry difference = %.3e\n", worst_omp);
+  // source-compatibility members the front-ends use (include/ktensor.h:161-170, utils/mttkrp.h:100,
+  // extern/rectangular_lsap/rectangular_lsap.h:44)
+  {
+    cals::Ktensor k(2, modes);
+    std::vector<double> f0(modes[0] * 2, 0.5), l2 = {3.0, 4.0};
+    k.set_factor(0, f0.data());
+    k.set_lambda(l2.data());
+    if (k.get_factor(0)(1, 1) != 0.5 || k.get_lambda()[1] != 4.0) return 4;
+    prm.mttkrp_lut = cals::mttkrp::read_lookup_table(modes, 1, true);
+    double cost[9] = {4, 1, 3, 2, 0, 5, 3, 2, 2};  // row-major 3 x 3, minimum 1 + 2 + 2 = 5
+    int64_t ra[3], cb[3];
+    if (solve_rectangular_linear_sum_assignment(3, 3, cost, false, ra, cb) != 0) return 5;
+    double tot = 0.0;
+    for (int i = 0; i < 3; i++) tot += cost[ra[i] * 3 + cb[i]];
+    if (tot != 5.0) return 6;
+  }
   return (worst <= 1e-9 && worst_als <= 1e-8 && worst_omp <= 1e-10) ? 0 : 1;
 }
