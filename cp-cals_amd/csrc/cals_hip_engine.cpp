@@ -1030,7 +1030,14 @@ int cals_hip_create_ex(cals_hip_engine **out, int n_modes, const int64_t *modes,
       pt_elems = std::max(pt_elems, nb_max * (size_t)L.Ap * CALS_BN);
     }
     if ((rc = dev_alloc_elems(e, &tp.Pt, pt_elems))) return rc;
-    HIPCHK(hipMalloc(&tp.Tbuf, t_elems * e->es));
+    if (hipMalloc(&tp.Tbuf, t_elems * e->es) != hipSuccess) {
+      // no room for T after all: run the three fused MTTKRPs (they work with any inner mode)
+      (void)hipGetLastError();
+      tp.Tbuf = nullptr;
+      tp.on = false;
+      tp.kind = 0;
+      for (int n = 0; n < 3; n++) tp.pair[n].on = false;
+    }
   }
   size_t ld_max = 0;
   for (int n = 0; n < n_modes; n++) ld_max = std::max<size_t>(ld_max, (size_t)e->lay[n].ldPart);
