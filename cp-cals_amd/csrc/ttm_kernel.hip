@@ -23,7 +23,12 @@
 //     reduction; G_first partials go through the same partial tiles + reduce_partials_kernel as the
 //     plain MTTKRP.
 // Two accumulator sets bound the tile height: MT <= 10 m-tiles in fp64, <= 20 in fp32; taller modes
-// are cut into M blocks (blockIdx.y), the first k_big of them MT tiles high, the others MT - 1.
+// are cut into M blocks, the first k_big of them MT tiles high, the others MT - 1, and every
+// workgroup walks all M blocks of its (column block, s range) one after the other, so that blocks
+// of different height cost every workgroup the same.
+// Operand order: fp32 feeds X as the MFMA's A operand and P as B; fp64 swaps them, which transposes
+// the accumulator tile so that the T flush and the partial tiles store whole 128-byte lines straight
+// from registers (see TtmBody); fp32 flushes T through a per-wave LDS transpose for the same reason.
 #include "mfma_common.h"
 
 namespace calship {
