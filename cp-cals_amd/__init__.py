@@ -62,6 +62,7 @@ EXPORTS = [
     "cals_hip_default_params", "cals_hip_create", "cals_hip_destroy", "cals_hip_last_error",
     "cals_hip_set_tensor", "cals_hip_set_params", "cals_hip_enqueue", "cals_hip_run",
     "cals_hip_model_result", "cals_hip_admit", "cals_hip_sweep", "cals_hip_evict",
+    "cals_hip_step", "cals_hip_get_report",
     "cals_hip_active_cols", "cals_hip_models_in_flight", "cals_hip_queue_size",
     "cals_hip_synchronize", "cals_hip_debug_mttkrp", "cals_hip_debug_mttkrp_path", "cals_hip_debug_get_factor",
     "cals_hip_debug_get_lambda", "cals_hip_debug_get_gramian", "cals_hip_debug_model_status",
@@ -101,6 +102,8 @@ def load_library():
     lib.cals_hip_admit.argtypes = [vp, C.POINTER(i64)]
     lib.cals_hip_sweep.argtypes = [vp, i64]
     lib.cals_hip_evict.argtypes = [vp, C.POINTER(i64)]
+    lib.cals_hip_step.argtypes = [vp, C.POINTER(i64), C.POINTER(i64)]
+    lib.cals_hip_get_report.argtypes = [vp, C.POINTER(Report)]
     for f in ("cals_hip_active_cols", "cals_hip_models_in_flight", "cals_hip_queue_size"):
         getattr(lib, f).argtypes = [vp]
         getattr(lib, f).restype = i64
@@ -264,6 +267,17 @@ class Engine:
         n = C.c_int64(0)
         self._chk(self.lib.cals_hip_evict(self.h, C.byref(n)))
         return n.value
+
+    def step(self):
+        """One iteration of run()'s loop; returns (admitted, evicted)."""
+        na, ne = C.c_int64(0), C.c_int64(0)
+        self._chk(self.lib.cals_hip_step(self.h, C.byref(na), C.byref(ne)))
+        return na.value, ne.value
+
+    def report(self):
+        rep = Report()
+        self._chk(self.lib.cals_hip_get_report(self.h, C.byref(rep)))
+        return rep
 
     def synchronize(self):
         self._chk(self.lib.cals_hip_synchronize(self.h))

@@ -1272,6 +1272,42 @@ int cals_hip_evict(cals_hip_engine *e, int64_t *n_evicted) {
   return evict(e, n_evicted);
 }
 
+// One iteration of cals_hip_run's loop (src/cals.cpp:182-362): admit what fits, one sweep with the
+// eviction rule, read the status back, evict + compress.  For callers that feed the queue while the
+// engine runs (cp-cals_amd/multi_gpu.py: work-queue hand-off between GPUs).
+int cals_hip_step(cals_hip_engine *e, int64_t *n_admitted, int64_t *n_evicted) {
+  if (!e) return CALS_HIP_ERR_ARG;
+  if (!e->has_tensor) return fail(e, CALS_HIP_ERR_STATE, "set_tensor first");
+  if (n_admitted) *n_admitted = 0;
+  if (n_evicted) *n_evicted = 0;
+  if (e->queue.empty() && e->registry.empty()) return CALS_HIP_OK;
+  int rc = admit(e, n_admitted);
+  if (rc) return rc;
+  if ((rc = sweep_once(e, true, true))) return rc;
+  if ((rc = fetch_status(e))) return rc;
+  if (e->prm.line_search)
+    for (auto t : e->registry) {
+      const int f = e->h_flags[e->models[t].slot];
+      if (f & 1) e->ls_performed++;
+      if (f & 2) e->ls_failed++;
+    }
+  return evict(e, n_evicted);
+}
+
+// counters accumulated since the last cals_hip_run / cals_hip_reset (iter = sweeps, times = 0)
+int cals_hip_get_report(const cals_hip_engine *e, cals_hip_report *rep) {
+  if (!e || !rep) return CALS_HIP_ERR_ARG;
+  rep->iter = e->sweeps;
+  rep->n_ktensors = e->n_ktensors;
+  rep->ktensor_comp_sum = e->comp_sum;
+  rep->ls_performed = e->ls_performed;
+  rep->ls_failed = e->ls_failed;
+  rep->X_norm = e->X_norm;
+  rep->total_ms = 0.0;
+  rep->loop_ms = 0.0;
+  return CALS_HIP_OK;
+}
+
 int cals_hip_run(cals_hip_engine *e, cals_hip_report *rep) {
   if (!e) return CALS_HIP_ERR_ARG;
   if (!e->has_tensor) return fail(e, CALS_HIP_ERR_STATE, "set_tensor first");

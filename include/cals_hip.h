@@ -154,6 +154,13 @@ int cals_hip_admit(cals_hip_engine *e, int64_t *n_admitted);
 int cals_hip_sweep(cals_hip_engine *e, int64_t n_sweeps);
 /* Eviction + compress phase, src/cals.cpp:336-362, applied to the current status. */
 int cals_hip_evict(cals_hip_engine *e, int64_t *n_evicted);
+/* One iteration of cals_hip_run's loop -- admit what fits, one sweep with the eviction rule of
+ * src/cals.cpp:336-354, evict + compress -- for callers that keep feeding the queue while the engine
+ * runs (work-queue hand-off between GPUs, cp-cals_amd/multi_gpu.py).  No-op when nothing is queued
+ * or in flight.  cals_hip_get_report: the counters of cals_hip_report accumulated so far (iter =
+ * sweeps done by this engine, times 0). */
+int cals_hip_step(cals_hip_engine *e, int64_t *n_admitted, int64_t *n_evicted);
+int cals_hip_get_report(const cals_hip_engine *e, cals_hip_report *rep);
 int64_t cals_hip_active_cols(const cals_hip_engine *e);  /* mkt.get_factor(0).get_cols() */
 int64_t cals_hip_models_in_flight(const cals_hip_engine *e);
 int64_t cals_hip_queue_size(const cals_hip_engine *e);

@@ -54,3 +54,45 @@ def test_round_robin_shards_and_aggregation_world2():
         assert r[2] == [res[0][1], res[1][1]]
         assert abs(r[3] - 30.0 / 2.0) < 1e-12          # (10 + 20) units / max(1 s, 2 s)
         assert abs(r[4] - 2.0) < 1e-12
+
+
+def _queue_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import random
+    import time
+    import torch.distributed as dist
+    import cp_cals_amd  # noqa: F401
+    from cp_cals_amd import multi_gpu
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    wq = multi_gpu.WorkQueue(57)
+    rnd = random.Random(rank)
+    got = []
+    while True:
+        ks = wq.claim(rnd.randint(1, 5))
+        if not ks:
+            break
+        got += ks
+        time.sleep(rnd.random() * 0.002 * (1 + 3 * rank))  # rank 1 is the slow one
+    dist.barrier()
+    q.put((rank, got))
+    dist.destroy_process_group()
+
+
+def test_work_queue_hands_out_every_index_once_world2():
+    """The pull-based hand-off of cp-cals_amd/multi_gpu.py: two ranks claim from one counter at
+    different speeds; together they get every index exactly once, the faster rank gets more."""
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_queue_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(res[0] + res[1]) == list(range(57))
+    assert len(res[0]) > len(res[1])
