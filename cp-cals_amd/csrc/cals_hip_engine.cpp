@@ -439,6 +439,7 @@ int launch_ttm(cals_hip_engine *e, int first, int64_t R, Geo *geo_out) {
   a.S = L.S;
   a.Mp = L.Mp;
   a.Ap = L.Ap;
+  a.A = L.A;
   a.R = (int)R;
   a.NB = g.NB;
   a.T = g.T;

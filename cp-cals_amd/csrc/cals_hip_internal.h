@@ -63,6 +63,7 @@ struct TtmArgs {
   int dtype;
   long long S, ldQ;
   int Mp, Ap, R;
+  int A;             // true size of mode a (rows >= A of Xp and Pt are zero padding)
   int NB, T;         // column blocks, team size (workgroups per column block and M block; split s)
   int ldPart;
   int grid;          // NB * T workgroups (1-D); each walks all m_blocks M blocks

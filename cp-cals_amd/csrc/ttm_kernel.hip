@@ -307,6 +307,7 @@ static __device__ __forceinline__ void run(const TtmArgs &a, const int m0, const
       blockIdx.x < 256 && n_units <= 512)
     trace = a.dbg_trace + ((blockIdx.x >> 5) * 2 + (wave >> 2)) * 2048;
 
+  const bool skip_q3 = a.A - 16 * (nAb - 1) <= 12;  // the last a-block has no valid row in k-step 3
   int buf = 0;
   auto unit_loop = [&]<bool LATE>() {
     unsigned long long dg_vm = 0, dg_bar = 0, dg_per = 0, dg_n = 0, dg_last = 0;  // CALS_DIAG sums
@@ -417,17 +418,26 @@ static __device__ __forceinline__ void run(const TtmArgs &a, const int m0, const
         }
       }
 
-      [&]<int... Is>(std::integer_sequence<int, Is...>) {
+      auto second_half = [&]<int I0, int... Is>(std::integer_sequence<int, Is...>) {
         (
             [&] {
-              P3::template step<C::H + Is>(tacc, ring, bq, base);
-              if constexpr (!LATE && Is < C::HH) {
-                if (fetch) issue_at.template operator()<Is>(src_slab, p_slab, q_row, dst);
+              constexpr int J = I0 + Is;  // step H + J
+              P3::template step<C::H + J>(tacc, ring, bq, base);
+              if constexpr (!LATE && J < C::HH) {
+                if (fetch) issue_at.template operator()<J>(src_slab, p_slab, q_row, dst);
               }
-              if constexpr (!LATE && Is == (C::NDMA < C::N - C::H - 1 ? C::NDMA : C::N - C::H - 1)) advance();
+              if constexpr (!LATE && J == (C::NDMA < C::N - C::H - 1 ? C::NDMA : C::N - C::H - 1)) advance();
             }(),
             ...);
-      }(std::make_integer_sequence<int, C::N - C::H>{});
+      };
+      // k-step 2 (rows 8..11 of the a-block), then k-step 3 (rows 12..15) -- which is all padding in
+      // the last a-block of a mode whose size leaves at most 12 rows there (300 = 18 x 16 + 12): its
+      // MFMAs would multiply zeros.  (Only when the DMA issue fits k-step 2, i.e. NDMA < MT.)
+      second_half.template operator()<0>(std::make_integer_sequence<int, MT>{});
+      if (!(C::NDMA < MT && skip_q3 && ab_c == nAb - 1))
+        second_half.template operator()<MT>(std::make_integer_sequence<int, C::N - C::H - MT>{});
+      else  // the operand reads already issued for k-step 3 must land before their registers are reused
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
       if (ab_c == nAb - 1) {
         if constexpr (LATE) {
