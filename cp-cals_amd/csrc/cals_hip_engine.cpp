@@ -33,6 +33,7 @@ struct HostModel {
   int slot = -1;
   int64_t col = -1;
   int64_t id = 0;  // MultiKtensor unique_kt_id
+  int ls_iter = 0;  // host mirror of LineSearchParams::iter for the error-checking methods
   cals_hip_model_status st{};
 };
 
@@ -329,19 +330,22 @@ Geo geometry(const cals_hip_engine *e, int mode, int64_t R) {
   return g;
 }
 
-int launch_mttkrp(cals_hip_engine *e, int mode, int64_t R, Geo *geo_out) {
+// fset: the factor buffers to contract with (default: the multi-factors; the error-checking line
+// search passes the extrapolated candidates)
+int launch_mttkrp(cals_hip_engine *e, int mode, int64_t R, Geo *geo_out, void *const *fset = nullptr) {
+  if (!fset) fset = e->factor;
   const ModeLayout &L = e->lay[mode];
   const Geo g = geometry(e, mode, R);
   const void *Q;
   long long ldQ;
   if (L.s_modes.size() == 1) {
-    Q = e->factor[L.s_modes[0]];
+    Q = fset[L.s_modes[0]];
     ldQ = e->modes[L.s_modes[0]];
   } else {
     KrpArgs k{};
     k.n = (int)L.s_modes.size();
     for (int i = 0; i < k.n; i++) {
-      k.F[i] = e->factor[L.s_modes[i]];
+      k.F[i] = fset[L.s_modes[i]];
       k.ld[i] = e->modes[L.s_modes[i]];
       k.dims[i] = (int)e->modes[L.s_modes[i]];
     }
@@ -357,7 +361,7 @@ int launch_mttkrp(cals_hip_engine *e, int mode, int64_t R, Geo *geo_out) {
   }
   MttkrpArgs a{};
   a.Xp = L.Xp;
-  a.P = e->factor[L.a_mode];
+  a.P = fset[L.a_mode];
   a.ldP = e->modes[L.a_mode];
   a.Q = Q;
   a.ldQ = ldQ;
@@ -499,6 +503,8 @@ LsArgs make_ls_args(cals_hip_engine *e) {
     a.gram[n] = e->gram[n];
   }
   a.dtype = e->dtype;
+  a.Gs = e->backup[0];
+  a.X_norm = e->X_norm;
   a.lambda = e->lambda;
   a.prev_lambda = e->prev_lambda;
   a.backup_lambda = e->backup_lambda;
@@ -568,7 +574,32 @@ int sweep_once(cals_hip_engine *e, bool evict_enabled, bool defer_changed = fals
     const bool pending = e->tree.t_second >= 0;  // a T shared across the sweep boundary
     if (pending) HIPCHK(hipMemsetAsync(e->tree.d_changed, 0, sizeof(int), e->stream));
     la.changed = pending ? e->tree.d_changed : nullptr;
-    HIPCHK(ls_launch(la, e->stream));
+    if (e->prm.line_search_method == 0) {
+      HIPCHK(ls_launch(la, e->stream));
+    } else if (e->prm.line_search_method == 2) {
+      // ls::ERROR_CHECKING_PARALLEL is an enum value the reference never dispatches
+      // (line_search.cpp:228-283 handles NO_ERROR_CHECKING and ERROR_CHECKING_SERIAL only): with it
+      // a run takes no line-search step at all.  Same here.
+    } else {
+      // ERROR_CHECKING: the host mirrors LineSearchParams::iter (it moves deterministically for
+      // these methods), so the extra MTTKRP is launched only when some model reaches its interval
+      bool event = false;
+      for (auto t : e->registry) {
+        HostModel &m = e->models[t];
+        if (++m.ls_iter == e->prm.line_search_interval) {
+          m.ls_iter = 0;
+          event = true;
+        }
+      }
+      HIPCHK(ls_ec_prepare_launch(la, e->stream));
+      if (event) {
+        Geo g;
+        if ((rc = launch_mttkrp(e, 0, R, &g, e->prev))) return rc;
+        HIPCHK(reduce_partials_launch(e->partial, g.T, e->lay[0].ldPart, (int)e->modes[0], (int)R,
+                                      e->backup[0], e->dtype, e->stream));
+        HIPCHK(ls_ec_decide_launch(la, e->stream));
+      }
+    }
     prof_end(e, pk);
     if (pending && defer_changed) {
       e->changed_deferred = true;  // cals_hip_run: the flag comes back with the status records
@@ -1214,9 +1245,10 @@ int cals_hip_dtype(const cals_hip_engine *e) {
 int cals_hip_set_params(cals_hip_engine *e, const cals_hip_params *p) {
   if (!e || !p) return CALS_HIP_ERR_ARG;
   if (p->max_iterations < 1) return fail(e, CALS_HIP_ERR_ARG, "max_iterations must be >= 1");
-  if (p->line_search && p->line_search_method != 0)
-    return fail(e, CALS_HIP_ERR_ARG,
-                "only ls::NO_ERROR_CHECKING runs on the device path (SURVEY.md section 8a15)");
+  if (p->line_search && (p->line_search_method < 0 || p->line_search_method > 2))
+    return fail(e, CALS_HIP_ERR_ARG, "line_search_method: 0 = NO_ERROR_CHECKING, 1 | 2 = ERROR_CHECKING");
+  if (p->line_search && p->line_search_method != e->prm.line_search_method && !e->registry.empty())
+    return fail(e, CALS_HIP_ERR_STATE, "the line-search method cannot change while models are in flight");
   if (p->line_search && p->line_search_interval < 1)
     return fail(e, CALS_HIP_ERR_ARG, "line_search_interval must be >= 1");
   e->prm = *p;

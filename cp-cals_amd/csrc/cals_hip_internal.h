@@ -168,9 +168,17 @@ struct LsArgs {
   double step;            // 0 => cbrt(iters)
   long long max_iter;
   int *changed;           // ls_kernel: set to 1 when any model's factors were rewritten (may be null)
+  // ERROR_CHECKING line search (ls_ec_*): MTTKRP of mode 0 with the extrapolated factors, I[0] x R
+  const void *Gs;
+  double X_norm;
 };
 hipError_t ls_snapshot_launch(const LsArgs &a, hipStream_t st);  // cals.cpp:203-211
 hipError_t ls_launch(const LsArgs &a, hipStream_t st);           // cals.cpp:310-331
+// ls::ERROR_CHECKING_SERIAL / _PARALLEL (src/utils/line_search.cpp:86-153, 262-271) in two steps
+// around an MTTKRP of the extrapolated factors: prepare writes them over the `prev` copies, decide
+// evaluates the error and keeps or drops them
+hipError_t ls_ec_prepare_launch(const LsArgs &a, hipStream_t st);
+hipError_t ls_ec_decide_launch(const LsArgs &a, hipStream_t st);
 
 struct FinishArgs {
   const int *slots;

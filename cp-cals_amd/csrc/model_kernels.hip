@@ -1221,6 +1221,162 @@ __global__ void __launch_bounds__(256) ls_kernel(const LsArgs a) {
   (void)s_lam;
 }
 
+// ---------------------------------------------------------------------------------------------
+// line search with error checking (ls::ERROR_CHECKING_SERIAL/_PARALLEL, line_search.cpp:86-153):
+// every `interval` model-iterations the extrapolation cur + step (cur - prev) is EVALUATED first and
+// kept only if its error is lower.  The reference reconstructs the tensor for that error
+// (error.cpp:7-30); here it comes from the same identity as the sweep's error,
+//   ||X - M||^2 = ||X||^2 + sum_ij l_i l_j (G0 o G1 o ... )_ij - 2 sum_c l_c <a_c, MTTKRP_0(M)_c>,
+// with one extra MTTKRP of the extrapolated factors (launched by the engine between the two
+// kernels, only on sweeps in which some model reaches its interval).
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) ls_ec_prepare_kernel(const LsArgs a) {
+  const int slot = a.slots[blockIdx.x];
+  const int tid = threadIdx.x;
+  const int col = a.mt.col[slot], r = a.mt.rank[slot];
+  const long long iters = a.mt.iters[slot];
+  const int ls_iter = a.mt.ls_iter[slot] + 1;
+  if (ls_iter != a.interval) {
+    if (tid == 0) {
+      a.mt.ls_iter[slot] = ls_iter;
+      a.mt.flags[slot] = 0;
+    }
+    return;
+  }
+  const double step = (a.step == 0.0) ? cbrt((double)iters) : a.step;
+  // ls_ktensor (= the prev copy) := cur + step (cur - prev); its lambda := the current lambda
+  for (int m = 0; m < a.n_modes; ++m) {
+    const long long n = (long long)a.I[m] * r, off = (long long)a.I[m] * col;
+    const T *cur = static_cast<const T *>(a.factor[m]);
+    T *old = static_cast<T *>(a.prev[m]);
+    for (long long e = tid; e < n; e += 256) {
+      const double c = (double)cur[off + e], diff = c - (double)old[off + e];
+      old[off + e] = (T)(c + step * diff);
+    }
+  }
+  if (tid < r) a.prev_lambda[col + tid] = a.lambda[col + tid];
+  if (tid == 0) {
+    a.mt.ls_iter[slot] = 0;
+    a.mt.flags[slot] = 1;  // extrapolated; decide adds "reversed" if the candidate is dropped
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) ls_ec_decide_kernel(const LsArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char ec_dyn[];
+  const int slot = a.slots[blockIdx.x];
+  if (!(a.mt.flags[slot] & 1)) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int col = a.mt.col[slot], r = a.mt.rank[slot];
+  double *H = reinterpret_cast<double *>(ec_dyn);   // r x r, ld CALS_RMAX: hadamard of the Gramians
+  double *tmp = H + CALS_RMAX * CALS_RMAX;          // one Gramian at a time
+  __shared__ double red[4];
+  __shared__ int s_accept;
+  // t2 = sum_ij l_i l_j prod_m (F_m^T F_m)_ij over the candidate's factors (in a.prev)
+  for (int m = 0; m < a.n_modes; ++m) {
+    if (wave == 0)
+      gramian_wave<T>(static_cast<const T *>(a.prev[m]) + (long long)a.I[m] * col, a.I[m], a.I[m], r,
+                      m == 0 ? H : tmp, lane);
+    __syncthreads();
+    if (m > 0)
+      for (int e = tid; e < r * r; e += 256) {
+        const int i = e % r, j = e / r;
+        H[i + CALS_RMAX * j] *= tmp[i + CALS_RMAX * j];
+      }
+    __syncthreads();
+  }
+  double t2 = 0.0, t3 = 0.0;
+  for (int e = tid; e < r * r; e += 256) {
+    const int i = e % r, j = e / r;
+    t2 += a.prev_lambda[col + i] * a.prev_lambda[col + j] * H[i + CALS_RMAX * j];
+  }
+  {
+    const int I0 = a.I[0];
+    const T *A0 = static_cast<const T *>(a.prev[0]) + (long long)I0 * col;
+    const T *G0 = static_cast<const T *>(a.Gs) + (long long)I0 * col;
+    for (long long e = tid; e < (long long)I0 * r; e += 256) {
+      const int c = (int)(e / I0);
+      t3 += a.prev_lambda[col + c] * (double)A0[e] * (double)G0[e];
+    }
+  }
+  t2 = wave_sum(t2);
+  t3 = wave_sum(t3);
+  if (lane == 0) red[wave] = t2;
+  __syncthreads();
+  t2 = red[0] + red[1] + red[2] + red[3];
+  __syncthreads();
+  if (lane == 0) red[wave] = t3;
+  __syncthreads();
+  t3 = red[0] + red[1] + red[2] + red[3];
+  // the reference evaluates the candidate against the FULL tensor, jackknife models included
+  const double error = sqrt(fmax(a.X_norm * a.X_norm + t2 - 2.0 * t3, 0.0));
+  if (tid == 0) s_accept = (error < a.mt.err[slot]) ? 1 : 0;
+  __syncthreads();
+  if (!s_accept) {
+    if (tid == 0) a.mt.flags[slot] = 3;  // extrapolated + reversed
+    return;
+  }
+  // keep it: compute_error left the candidate normalised (factor 0 scaled by lambda first, then every
+  // column of every mode to unit 2-norm, ktensor.cpp:85-107); the factors are copied, lambda is NOT
+  // (line_search.cpp:121-127)
+  for (int m = 0; m < a.n_modes; ++m) {
+    for (int c = wave; c < r; c += 4) {
+      const T *src = static_cast<const T *>(a.prev[m]) + (long long)a.I[m] * (col + c);
+      T *dst = static_cast<T *>(a.factor[m]) + (long long)a.I[m] * (col + c);
+      const double lc = (m == 0) ? a.prev_lambda[col + c] : 1.0;
+      double ss = 0.0;
+      for (int i = lane; i < a.I[m]; i += 64) {
+        const double x = lc * (double)src[i];
+        ss += x * x;
+      }
+      const double s = 1.0 / sqrt(wave_sum(ss));
+      for (int i = lane; i < a.I[m]; i += 64) dst[i] = (T)(s * (lc * (double)src[i]));
+    }
+  }
+  __threadfence_block();
+  __syncthreads();
+  for (int m = wave; m < a.n_modes; m += 4)
+    gramian_wave<T>(static_cast<const T *>(a.factor[m]) + (long long)a.I[m] * col, a.I[m], a.I[m], r,
+                    a.gram[m] + CALS_RMAX * (long long)col, lane);
+  if (tid == 0) {
+    a.mt.err[slot] = error;
+    const double of = a.mt.fit[slot];
+    a.mt.old_fit[slot] = of;
+    a.mt.fit[slot] = 1.0 - fabs(error) / a.X_norm;
+    if (a.changed) atomicOr(a.changed, 1);
+  }
+}
+
+hipError_t ls_ec_prepare_launch(const LsArgs &a, hipStream_t st) {
+  if (a.n_slots <= 0) return hipSuccess;
+  if (a.dtype == CALS_F32)
+    hipLaunchKernelGGL(ls_ec_prepare_kernel<float>, dim3(a.n_slots), dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL(ls_ec_prepare_kernel<double>, dim3(a.n_slots), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+
+hipError_t ls_ec_decide_launch(const LsArgs &a, hipStream_t st) {
+  if (a.n_slots <= 0) return hipSuccess;
+  const size_t dyn = (size_t)2 * CALS_RMAX * CALS_RMAX * sizeof(double);
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void *>(&ls_ec_decide_kernel<float>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+    hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void *>(&ls_ec_decide_kernel<double>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+    if (e1 != hipSuccess) return e1;
+    if (e2 != hipSuccess) return e2;
+    attr = true;
+  }
+  if (a.dtype == CALS_F32)
+    hipLaunchKernelGGL(ls_ec_decide_kernel<float>, dim3(a.n_slots), dim3(256), dyn, st, a);
+  else
+    hipLaunchKernelGGL(ls_ec_decide_kernel<double>, dim3(a.n_slots), dim3(256), dyn, st, a);
+  return hipGetLastError();
+}
+
 hipError_t ls_snapshot_launch(const LsArgs &a, hipStream_t st) {
   if (a.n_slots <= 0) return hipSuccess;
   if (a.dtype == CALS_F32)

@@ -44,7 +44,9 @@ typedef struct {
   int line_search;          /* 0 */
   int line_search_interval; /* 5 */
   double line_search_step;  /* 0 => cbrt(model iteration), src/cals.cpp:317-318 */
-  int line_search_method;   /* 0 = ls::NO_ERROR_CHECKING (only method on the device path) */
+  int line_search_method;   /* ls::LS_METHOD: 0 NO_ERROR_CHECKING, 1 ERROR_CHECKING_SERIAL (the candidate's error
+                             * from one extra MTTKRP), 2 ERROR_CHECKING_PARALLEL (never dispatched by the
+                             * reference, line_search.cpp:228-283: no step is taken; same here) */
   int force_max_iter;       /* 0 */
   int always_evict_first;   /* 0 */
 } cals_hip_params;

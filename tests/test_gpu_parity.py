@@ -200,6 +200,26 @@ def test_line_search_vs_oracle(cc, oracle, inputs):
     _assert_models_match(gm, om, ro.X_norm ** 2)
 
 
+@pytest.mark.parametrize("method,interval,noise", [(1, 5, 0.1), (2, 3, 0.05), (1, 2, 0.3)])
+def test_error_checking_line_search_vs_oracle(cc, oracle, inputs, method, interval, noise):
+    """ls::ERROR_CHECKING_SERIAL / _PARALLEL (line_search.cpp:86-153): the extrapolation is evaluated
+    and kept only if its error is lower.  Same accept / reject decisions, iteration counts and
+    factors as the oracle (whose candidate error is the reconstruction's; the device's comes from an
+    MTTKRP of the candidate)."""
+    modes = [22, 19, 17]
+    ranks = [2, 3, 4, 5, 9, 14, 1, 20]
+    X = inputs.low_rank_tensor(modes, 6, seed=31)[0] + noise * inputs.tensor(modes, 8)
+    gm, om, rep, ro = _run_both(cc, oracle, inputs, modes, ranks, X, 40, force_max_iter=0, tol=1e-7,
+                                line_search=1, line_search_interval=interval, line_search_method=method)
+    assert rep.iter == ro.iter
+    assert (rep.ls_performed, rep.ls_failed) == (ro.ls_performed, ro.ls_failed)
+    if method == 1:
+        assert rep.ls_performed > 0 and 0 < rep.ls_failed < rep.ls_performed  # both outcomes occur
+    else:
+        assert rep.ls_performed == 0  # the reference never dispatches ERROR_CHECKING_PARALLEL
+    _assert_models_match(gm, om, ro.X_norm ** 2)
+
+
 @pytest.mark.parametrize("ls", [0, 1])
 def test_queue_eviction_compress_vs_oracle(cc, oracle, inputs, ls):
     """buffer_size < sum of ranks, tol-based convergence: admission order, eviction sweep, compress
@@ -226,7 +246,7 @@ def test_rejects_bad_input_loudly(cc, inputs):
     with pytest.raises(cc.CalsHipError):
         e.sweep(1)                                     # no tensor yet
     with pytest.raises(cc.CalsHipError):
-        e.set_params(cc.default_params(line_search=1, line_search_method=1))
+        e.set_params(cc.default_params(line_search=1, line_search_method=3))
     e.close()
 
 

@@ -100,7 +100,8 @@ def test_random_queue_life_cycle(cc, oracle, inputs, modes, ranks, buffer, plan,
     try:
         X = inputs.low_rank_tensor(modes, 5, seed=seed % 1000)[0] + 0.05 * inputs.tensor(modes, seed % 977)
         base = make_models(inputs, modes, ranks, seed=1 + seed % 991)
-        kw = dict(max_iterations=30, tol=tol, line_search=ls, line_search_interval=3)
+        kw = dict(max_iterations=30, tol=tol, line_search=ls, line_search_interval=3,
+                  line_search_method=(seed >> 3) & 1)  # NO_ERROR_CHECKING or ERROR_CHECKING_SERIAL
         e = cc.Engine(modes, buffer)
         e.set_tensor(X)
         e.set_params(cc.default_params(**kw))

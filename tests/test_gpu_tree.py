@@ -108,6 +108,21 @@ def test_tree_line_search_vs_oracle(cc, oracle, inputs, plan):
     _assert_models_match(gm, om, ro.X_norm ** 2)
 
 
+def test_tree_error_checking_line_search_vs_oracle(cc, oracle, inputs, plan):
+    """An accepted ERROR_CHECKING step rewrites a model's factors: a T pending across the sweep
+    boundary has to be dropped exactly as for the other method."""
+    modes, ranks = [22, 19, 17], [2, 3, 4, 5, 9, 14, 1, 20]
+    X = inputs.low_rank_tensor(modes, 6, seed=31)[0] + 0.1 * inputs.tensor(modes, 8)
+    # tolerance-driven stop: a converged model's candidates differ from its error by rounding only,
+    # and the accept/reject decision would then depend on the association of the sums
+    gm, om, rep, ro = _run_both(cc, oracle, inputs, modes, ranks, X, 40, force_max_iter=0, tol=1e-7,
+                                line_search=1, line_search_interval=5, line_search_method=1)
+    assert rep.iter == ro.iter
+    assert (rep.ls_performed, rep.ls_failed) == (ro.ls_performed, ro.ls_failed)
+    assert rep.ls_performed > rep.ls_failed > 0
+    _assert_models_match(gm, om, ro.X_norm ** 2)
+
+
 def test_tree_jackknife_models_vs_oracle(cc, oracle, inputs, plan):
     modes, comp = [20, 9, 12], 5
     X = inputs.low_rank_tensor(modes, comp, seed=21)[0]
