@@ -29,7 +29,7 @@ class Params(C.Structure):
         ("max_iterations", C.c_int64), ("tol", C.c_double), ("line_search", C.c_int),
         ("line_search_interval", C.c_int), ("line_search_step", C.c_double),
         ("line_search_method", C.c_int), ("force_max_iter", C.c_int),
-        ("always_evict_first", C.c_int),
+        ("always_evict_first", C.c_int), ("update_method", C.c_int),
     ]
 
 
@@ -37,7 +37,7 @@ class Report(C.Structure):
     _fields_ = [
         ("iter", C.c_int64), ("n_ktensors", C.c_int64), ("ktensor_comp_sum", C.c_int64),
         ("ls_performed", C.c_int64), ("ls_failed", C.c_int64), ("X_norm", C.c_double),
-        ("total_ms", C.c_double), ("loop_ms", C.c_double),
+        ("total_ms", C.c_double), ("loop_ms", C.c_double), ("nnls_status", C.c_int),
     ]
 
 

@@ -78,8 +78,6 @@ CalsReport cp_cals(const Tensor &X, KtensorQueue &kt_queue, CalsParams &p) {
   if (!p.cuda)
     throw std::runtime_error("cp_cals: this library has only the MI355X device path (no CPU "
                              "fallback); CalsParams::cuda must stay true");
-  if (p.update_method != update::UNCONSTRAINED)
-    throw std::runtime_error("cp_cals: only update::UNCONSTRAINED runs on the device path");
   CalsReport rep;
   rep.tensor_rank = X.get_rank();
   rep.n_modes = X.get_n_modes();
@@ -110,6 +108,7 @@ CalsReport cp_cals(const Tensor &X, KtensorQueue &kt_queue, CalsParams &p) {
   hp.line_search_method = (int)p.line_search_method;
   hp.force_max_iter = p.force_max_iter ? 1 : 0;
   hp.always_evict_first = p.always_evict_first ? 1 : 0;
+  hp.update_method = (p.update_method == update::NNLS) ? 1 : 0;
   if ((rc = cals_hip_set_params(g.e, &hp))) fail(g.e, "cals_hip_set_params", rc);
 
   std::vector<std::reference_wrapper<Ktensor>> kts;

@@ -106,6 +106,14 @@ struct cals_hip_engine {
   double *gram[CALS_HIP_MAX_MODES] = {nullptr};
   double *lambda = nullptr, *prev_lambda = nullptr, *backup_lambda = nullptr;
   bool ls_allocated = false;
+  // NNLS update (update_method == 1): Ktensor::active_set per mode (+ the line search's backup copy),
+  // the per-row <x, g> buffer between nnls_kernel and update_kernel, the sticky status word
+  unsigned long long *act[CALS_HIP_MAX_MODES] = {nullptr};
+  unsigned long long *act_backup[CALS_HIP_MAX_MODES] = {nullptr};
+  double *rowdot = nullptr;
+  int *d_nnls_status = nullptr;
+  int nnls_status = 0;
+  bool nnls_allocated = false, nnls_ls_allocated = false;
   void *partial = nullptr;
   size_t partial_elems = 0;
   void *krp_ws = nullptr;
@@ -312,6 +320,27 @@ int alloc_ls(cals_hip_engine *e) {
   return CALS_HIP_OK;
 }
 
+int alloc_nnls(cals_hip_engine *e) {
+  int rc;
+  if (!e->nnls_allocated) {
+    int64_t imax = 1;
+    for (int n = 0; n < e->n_modes; n++) {
+      imax = std::max(imax, e->modes[n]);
+      if ((rc = dev_alloc(e, &e->act[n], (size_t)(e->modes[n] * e->buffer)))) return rc;
+    }
+    if ((rc = dev_alloc(e, &e->rowdot, (size_t)(imax * e->max_slots)))) return rc;
+    if ((rc = dev_alloc(e, &e->d_nnls_status, 1))) return rc;
+    HIPCHK(hipMemsetAsync(e->d_nnls_status, 0, sizeof(int), e->stream));
+    e->nnls_allocated = true;
+  }
+  if (e->prm.line_search && !e->nnls_ls_allocated) {
+    for (int n = 0; n < e->n_modes; n++)
+      if ((rc = dev_alloc(e, &e->act_backup[n], (size_t)(e->modes[n] * e->buffer)))) return rc;
+    e->nnls_ls_allocated = true;
+  }
+  return CALS_HIP_OK;
+}
+
 // MTTKRP launch geometry for `mode` at R active columns
 struct Geo {
   int NB, T;
@@ -512,6 +541,11 @@ LsArgs make_ls_args(cals_hip_engine *e) {
   a.interval = e->prm.line_search_interval;
   a.step = e->prm.line_search_step;
   a.max_iter = e->prm.max_iterations;
+  if (e->prm.update_method == 1 && e->nnls_ls_allocated)
+    for (int n = 0; n < e->n_modes; n++) {
+      a.act[n] = e->act[n];
+      a.act_backup[n] = e->act_backup[n];
+    }
   return a;
 }
 
@@ -522,6 +556,8 @@ int sweep_once(cals_hip_engine *e, bool evict_enabled, bool defer_changed = fals
   if (rc) return rc;
   const int64_t R = e->end;
   const int ns = (int)e->registry.size();
+  if (e->prm.update_method == 1 && (!e->nnls_allocated || (e->prm.line_search && !e->nnls_ls_allocated)))
+    return fail(e, CALS_HIP_ERR_STATE, "internal: NNLS state missing");
   if (e->prm.line_search) {
     if ((rc = alloc_ls(e))) return rc;
     LsArgs la = make_ls_args(e);
@@ -565,6 +601,24 @@ int sweep_once(cals_hip_engine *e, bool evict_enabled, bool defer_changed = fals
     if (!by_contract)
       HIPCHK(reduce_partials_launch(e->partial, g.T, e->lay[n].ldPart, (int)e->modes[n], (int)R,
                                     e->factor[n], e->dtype, e->stream));
+    if (e->prm.update_method == 1) {  // update::NNLS (cals.cpp:244-248)
+      NnlsArgs q{};
+      q.slots = e->d_slots;
+      q.n_slots = ns;
+      q.mt = e->mt;
+      q.factor = e->factor[n];
+      q.dtype = e->dtype;
+      q.I = (int)e->modes[n];
+      for (int m = 0; m < e->n_modes; m++) q.gram[m] = e->gram[m];
+      q.n_modes = e->n_modes;
+      q.mode = n;
+      q.act = e->act[n];
+      q.rowdot = e->rowdot;
+      q.status = e->d_nnls_status;
+      q.rmax = rank_max;
+      HIPCHK(nnls_launch(q, e->stream));
+      u.rowdot = e->rowdot;
+    }
     HIPCHK(update_launch(u, rank_max, e->stream));
     prof_end(e, pk);
   }
@@ -647,7 +701,7 @@ int fetch_status(cals_hip_engine *e) {
     HIPCHK(hipHostMalloc((void **)&e->h_status, e->status_cap * sizeof(StatusRec), hipHostMallocDefault));
   }
   HIPCHK(pack_status_launch(e->d_slots, (int)ns, e->mt, e->changed_deferred ? e->tree.d_changed : nullptr,
-                            e->d_status, e->stream));
+                            e->nnls_allocated ? e->d_nnls_status : nullptr, e->d_status, e->stream));
   HIPCHK(hipMemcpyAsync(e->h_status, e->d_status, (ns + 1) * sizeof(StatusRec), hipMemcpyDeviceToHost,
                         e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
@@ -655,6 +709,7 @@ int fetch_status(cals_hip_engine *e) {
     if (e->h_status[0].flags) tree_invalidate(e);
     e->changed_deferred = false;
   }
+  e->nnls_status |= e->h_status[0].pad;
   for (size_t k = 0; k < ns; k++) {
     const StatusRec &r = e->h_status[1 + k];
     const size_t slot = (size_t)e->models[e->registry[k]].slot;
@@ -749,6 +804,11 @@ int compress(cals_hip_engine *e) {
         HIPCHK(move_columns_launch(e->prev[n], e->dtype, e->modes[n], col, r, off, e->stream));
         HIPCHK(move_columns_launch(e->backup[n], e->dtype, e->modes[n], col, r, off, e->stream));
       }
+      // the active sets of a model sit in its first column (64-bit words moved as such)
+      if (e->nnls_allocated)
+        HIPCHK(move_columns_launch(e->act[n], CALS_F64, e->modes[n], col, 1, off, e->stream));
+      if (e->nnls_ls_allocated)
+        HIPCHK(move_columns_launch(e->act_backup[n], CALS_F64, e->modes[n], col, 1, off, e->stream));
     }
     HIPCHK(move_columns_launch(e->lambda, CALS_F64, 1, col, r, off, e->stream));
     if (e->ls_allocated) {
@@ -842,6 +902,17 @@ int admit(cals_hip_engine *e, int64_t *n_admitted) {
     HIPCHK(hipMemcpyAsync(d_new, new_slots.data(), new_slots.size() * sizeof(int),
                           hipMemcpyHostToDevice, e->stream));
     HIPCHK(init_slots_launch(d_desc, (int)new_slots.size(), e->mt, e->stream));
+    if (e->prm.update_method == 1) {
+      int rc2 = alloc_nnls(e);
+      if (rc2) return rc2;
+      NnlsResetArgs ra{};
+      for (int n = 0; n < e->n_modes; n++) {
+        ra.act[n] = e->act[n];
+        ra.I[n] = (int)e->modes[n];
+      }
+      ra.n_modes = e->n_modes;
+      HIPCHK(nnls_reset_launch(d_desc, (int)new_slots.size(), ra, e->stream));
+    }
     GramInitArgs g{};
     g.slots = d_new;
     g.n_slots = (int)new_slots.size();
@@ -895,6 +966,7 @@ void cals_hip_default_params(cals_hip_params *p) {
   p->line_search_method = 0;
   p->force_max_iter = 0;
   p->always_evict_first = 0;
+  p->update_method = 0;
 }
 
 int cals_hip_device_count(void) {
@@ -1139,6 +1211,12 @@ int cals_hip_destroy(cals_hip_engine *e) {
   fr(e->lambda);
   fr(e->prev_lambda);
   fr(e->backup_lambda);
+  for (int n = 0; n < CALS_HIP_MAX_MODES; n++) {
+    fr(e->act[n]);
+    fr(e->act_backup[n]);
+  }
+  fr(e->rowdot);
+  fr(e->d_nnls_status);
   fr(e->partial);
   fr(e->tree.Tbuf);
   fr(e->tree.Pt);
@@ -1251,6 +1329,12 @@ int cals_hip_set_params(cals_hip_engine *e, const cals_hip_params *p) {
     return fail(e, CALS_HIP_ERR_STATE, "the line-search method cannot change while models are in flight");
   if (p->line_search && p->line_search_interval < 1)
     return fail(e, CALS_HIP_ERR_ARG, "line_search_interval must be >= 1");
+  if (p->update_method < 0 || p->update_method > 1)
+    return fail(e, CALS_HIP_ERR_ARG, "update_method: 0 = UNCONSTRAINED, 1 = NNLS");
+  if (p->update_method != e->prm.update_method && !e->registry.empty())
+    return fail(e, CALS_HIP_ERR_STATE, "the update method cannot change while models are in flight");
+  if (p->update_method == 1 && p->line_search && !e->prm.line_search && !e->registry.empty())
+    return fail(e, CALS_HIP_ERR_STATE, "NNLS: line search cannot be switched on while models are in flight");
   e->prm = *p;
   return CALS_HIP_OK;
 }
@@ -1338,6 +1422,7 @@ int cals_hip_get_report(const cals_hip_engine *e, cals_hip_report *rep) {
   rep->X_norm = e->X_norm;
   rep->total_ms = 0.0;
   rep->loop_ms = 0.0;
+  rep->nnls_status = e->nnls_status;
   return CALS_HIP_OK;
 }
 
@@ -1376,6 +1461,7 @@ int cals_hip_run(cals_hip_engine *e, cals_hip_report *rep) {
     rep->X_norm = e->X_norm;
     rep->total_ms = t1 - t0;
     rep->loop_ms = t1 - t_loop;
+    rep->nnls_status = e->nnls_status;
   }
   return CALS_HIP_OK;
 }

@@ -130,8 +130,37 @@ struct UpdateArgs {
   const double *jk_norms;
   unsigned long long *dbg_trace;  // CALS_DIAG builds: phase stamps of the first rank-20 model (mode 0)
   int xld;             // set by update_launch: > 0 = leading dimension of the LDS-resident panel
+  // NNLS update: nnls_launch already replaced the MTTKRP result in `factor` by the constrained
+  // solution and left <x_row, g_row> here ([n_slots][I]); the kernel then skips Cholesky + solves
+  const double *rowdot;
 };
 hipError_t update_launch(const UpdateArgs &a, int rmax_needed, hipStream_t st);
+
+// update::update_factor_non_negative_constrained for one mode (nnls_kernel.hip)
+struct NnlsArgs {
+  const int *slots;
+  int n_slots;
+  ModelTable mt;
+  void *factor;        // in: MTTKRP result, out: constrained solution (element type = dtype)
+  int dtype;
+  int I;
+  double *gram[CALS_MAX_MODES];
+  int n_modes, mode;
+  unsigned long long *act;  // Ktensor::active_set of this mode: [I x buffer], the mask of (row, model)
+                            // at row + I * col(model); bit i set = constraint i active
+  double *rowdot;      // out: [n_slots][I]
+  int *status;         // sticky OR: 1 Cholesky failure in the main loop, 2 exchange bound reached
+  int rmax;            // largest rank in flight (sizes the LDS tiles)
+  int chunks;          // set by nnls_launch: workgroups per model
+};
+hipError_t nnls_launch(const NnlsArgs &a, hipStream_t st);
+struct NnlsResetArgs {
+  unsigned long long *act[CALS_MAX_MODES];
+  int I[CALS_MAX_MODES];
+  int n_modes;
+};
+hipError_t nnls_reset_launch(const int *desc, int n, const NnlsResetArgs &a, hipStream_t st);
+
 // deterministic reduction of the MTTKRP split partials into the multi-factor of the mode
 hipError_t reduce_partials_launch(const void *partial, int T, int ldPart, int I, int R,
                                   void *factor, int dtype, hipStream_t st);
@@ -171,6 +200,8 @@ struct LsArgs {
   // ERROR_CHECKING line search (ls_ec_*): MTTKRP of mode 0 with the extrapolated factors, I[0] x R
   const void *Gs;
   double X_norm;
+  // NNLS: Ktensor::copy carries the active sets along (src/ktensor.cpp:174); null otherwise
+  unsigned long long *act[CALS_MAX_MODES], *act_backup[CALS_MAX_MODES];
 };
 hipError_t ls_snapshot_launch(const LsArgs &a, hipStream_t st);  // cals.cpp:203-211
 hipError_t ls_launch(const LsArgs &a, hipStream_t st);           // cals.cpp:310-331
@@ -193,12 +224,13 @@ hipError_t finish_launch(const FinishArgs &a, hipStream_t st);   // cals.cpp:336
 
 // per-sweep status read-back of cals_hip_run: one packed record per in-flight model (registry order)
 struct StatusRec {
-  int flags, pad;      // pad = slot (header record: flags = line-search "changed" flag)
+  int flags, pad;      // pad = slot (header record: flags = line-search "changed" flag, pad = NNLS status)
   long long iters;     // header record: number of records that follow
   double err, fit, old_fit;
 };
+// nnls_status (may be null) lands in the header record's `pad`
 hipError_t pack_status_launch(const int *slots, int n, const ModelTable &mt, const int *changed,
-                              StatusRec *out, hipStream_t st);
+                              const int *nnls_status, StatusRec *out, hipStream_t st);
 
 // set-up kernels
 // X: src_dtype elements (as uploaded), Xp: dst_dtype elements

@@ -187,11 +187,14 @@ __device__ __attribute__((noinline)) void update_body(const UpdateArgs &a, int s
   __syncthreads();
 
   UPD_STAMP(1);
+  // NNLS update: the panel already holds the constrained solution (nnls_kernel.hip)
+  const double *rowdot = a.rowdot ? a.rowdot + (long long)I * blockIdx.x : nullptr;
+  const bool solved = rowdot != nullptr;
   // dpotrf('L') restated as unblocked dpotf2 (lane = row; every wave computes, wave 0 writes).
   // info != 0: stop, keep going with whatever is in H, as the reference does
   // (update.cpp:183-185 only logs).
   int info = 0;
-  for (int j = 0; j < r; ++j) {
+  for (int j = 0; j < (solved ? 0 : r); ++j) {
     double ajj = Hs[j + RMAX * j];
     for (int k = 0; k < j; ++k) ajj -= Hs[j + RMAX * k] * Hs[j + RMAX * k];
     if (!(ajj > 0.0)) {
@@ -218,7 +221,7 @@ __device__ __attribute__((noinline)) void update_body(const UpdateArgs &a, int s
   }
   __syncthreads();
   if (tid < r) sh.dinv[tid] = 1.0 / Hs[tid + RMAX * tid];
-  if (tid == 0) a.mt.potrf_info[slot] = info;
+  if (tid == 0 && !solved) a.mt.potrf_info[slot] = info;
   __syncthreads();
   const double *dinv = sh.dinv;
   UPD_STAMP(2);
@@ -252,29 +255,36 @@ __device__ __attribute__((noinline)) void update_body(const UpdateArgs &a, int s
       x[c] = (c < r) ? (double)fac[i + (long long)I * c] : 0.0;
       g[c] = x[c];
     }
-    // B := B * inv(L^T)   (dtrsm Right, Lower, Trans)
+    if (!solved) {
+      // B := B * inv(L^T)   (dtrsm Right, Lower, Trans)
 #pragma unroll
-    for (int k = 0; k < RMAX; ++k) {
-      if (k < r) {
-        x[k] = dinv[k] * x[k];
+      for (int k = 0; k < RMAX; ++k) {
+        if (k < r) {
+          x[k] = dinv[k] * x[k];
 #pragma unroll
-        for (int j = k + 1; j < RMAX; ++j)
-          if (j < r) x[j] -= Hs[j + RMAX * k] * x[k];
+          for (int j = k + 1; j < RMAX; ++j)
+            if (j < r) x[j] -= Hs[j + RMAX * k] * x[k];
+        }
       }
-    }
-    // B := B * inv(L)     (dtrsm Right, Lower, NoTrans)
+      // B := B * inv(L)     (dtrsm Right, Lower, NoTrans)
 #pragma unroll
-    for (int j = RMAX - 1; j >= 0; --j) {
-      if (j < r) {
+      for (int j = RMAX - 1; j >= 0; --j) {
+        if (j < r) {
 #pragma unroll
-        for (int k = j + 1; k < RMAX; ++k)
-          if (k < r) x[j] -= Hs[k + RMAX * j] * x[k];
-        x[j] = dinv[j] * x[j];
+          for (int k = j + 1; k < RMAX; ++k)
+            if (k < r) x[j] -= Hs[k + RMAX * j] * x[k];
+          x[j] = dinv[j] * x[j];
+        }
       }
     }
     if (i == jkf) {
 #pragma unroll
       for (int c = 0; c < RMAX; ++c) x[c] *= 0.0;
+    }
+    if (solved) {  // <x, g> of this row as nnls_kernel left it; g itself is gone
+#pragma unroll
+      for (int c = 0; c < RMAX; ++c) g[c] = 0.0;
+      if (i != jkf) t3 += rowdot[i];
     }
 #pragma unroll
     for (int c = 0; c < RMAX; ++c) {
@@ -472,9 +482,12 @@ __device__ __attribute__((noinline)) void update_body_lds(const UpdateArgs &a, i
   __syncthreads();
   UPD_STAMP(1);
 
+  // NNLS update: the panel already holds the constrained solution (nnls_kernel.hip)
+  const double *rowdot = a.rowdot ? a.rowdot + (long long)I * blockIdx.x : nullptr;
+  const bool solved = rowdot != nullptr;
   // dpotrf('L') restated as unblocked dpotf2 on wave 0 (lane = row).  info != 0: stop, keep going
   // with whatever is in H, as the reference does (update.cpp:183-185 only logs).
-  if (wave == 0) {
+  if (wave == 0 && !solved) {
     int info = 0;
     for (int j = 0; j < r; ++j) {
       const bool below = lane > j && lane < r;
@@ -533,27 +546,34 @@ __device__ __attribute__((noinline)) void update_body_lds(const UpdateArgs &a, i
       x[c] = (c < r) ? (double)fac[i + (long long)I * c] : 0.0;
       g[c] = x[c];
     }
+    if (!solved) {
 #pragma unroll
-    for (int k = 0; k < RMAX; ++k) {
-      if (k < r) {
-        x[k] = dinv[k] * x[k];
+      for (int k = 0; k < RMAX; ++k) {
+        if (k < r) {
+          x[k] = dinv[k] * x[k];
 #pragma unroll
-        for (int j = k + 1; j < RMAX; ++j)
-          if (j < r) x[j] -= Hs[j + RMAX * k] * x[k];
+          for (int j = k + 1; j < RMAX; ++j)
+            if (j < r) x[j] -= Hs[j + RMAX * k] * x[k];
+        }
       }
-    }
 #pragma unroll
-    for (int j = RMAX - 1; j >= 0; --j) {
-      if (j < r) {
+      for (int j = RMAX - 1; j >= 0; --j) {
+        if (j < r) {
 #pragma unroll
-        for (int k = j + 1; k < RMAX; ++k)
-          if (k < r) x[j] -= Hs[k + RMAX * j] * x[k];
-        x[j] = dinv[j] * x[j];
+          for (int k = j + 1; k < RMAX; ++k)
+            if (k < r) x[j] -= Hs[k + RMAX * j] * x[k];
+          x[j] = dinv[j] * x[j];
+        }
       }
     }
     if (i == jkf) {
 #pragma unroll
       for (int c = 0; c < RMAX; ++c) x[c] *= 0.0;
+    }
+    if (solved) {  // <x, g> of this row as nnls_kernel left it; g itself is gone
+#pragma unroll
+      for (int c = 0; c < RMAX; ++c) g[c] = 0.0;
+      if (i != jkf) t3 += rowdot[i];
     }
 #pragma unroll
     for (int c = 0; c < RMAX; ++c) {
@@ -744,7 +764,10 @@ __device__ __attribute__((noinline)) void update_body_big(const UpdateArgs &a, i
     Hb[i + RM * j] = h;
   }
   __syncthreads();
-  if (wave == 0) {  // dpotf2 order, lane = row (r <= 64 = one wave)
+  // NNLS update: the panel already holds the constrained solution (nnls_kernel.hip)
+  const double *rowdot = a.rowdot ? a.rowdot + (long long)a.I * blockIdx.x : nullptr;
+  const bool solved = rowdot != nullptr;
+  if (wave == 0 && !solved) {  // dpotf2 order, lane = row (r <= 64 = one wave)
     int info = 0;
     for (int j = 0; j < r; ++j) {
       const bool below = lane > j && lane < r;
@@ -782,29 +805,35 @@ __device__ __attribute__((noinline)) void update_body_big(const UpdateArgs &a, i
     asm volatile("" ::: "memory");
 #pragma unroll
     for (int c = 0; c < RM; ++c) x[c] = (c < r) ? (double)fac[i + (long long)I * c] : 0.0;
+    if (!solved) {
 #pragma unroll
-    for (int k = 0; k < RM; ++k) {
-      if (k < r) {
-        x[k] = dinv[k] * x[k];
+      for (int k = 0; k < RM; ++k) {
+        if (k < r) {
+          x[k] = dinv[k] * x[k];
 #pragma unroll
-        for (int j = k + 1; j < RM; ++j)
-          if (j < r) x[j] -= Hb[j + RM * k] * x[k];
+          for (int j = k + 1; j < RM; ++j)
+            if (j < r) x[j] -= Hb[j + RM * k] * x[k];
+        }
       }
-    }
+      if (i != jkf) {  // a jackknife model's zeroed fiber (below) has no share in term3
 #pragma unroll
-    for (int c = 0; c < RM; ++c)
-      if (c < r) t3 += x[c] * x[c];
-#pragma unroll
-    for (int j = RM - 1; j >= 0; --j) {
-      if (j < r) {
-#pragma unroll
-        for (int k = j + 1; k < RM; ++k)
-          if (k < r) x[j] -= Hb[k + RM * j] * x[k];
-        x[j] = dinv[j] * x[j];
+        for (int c = 0; c < RM; ++c)
+          if (c < r) t3 += x[c] * x[c];
       }
+#pragma unroll
+      for (int j = RM - 1; j >= 0; --j) {
+        if (j < r) {
+#pragma unroll
+          for (int k = j + 1; k < RM; ++k)
+            if (k < r) x[j] -= Hb[k + RM * j] * x[k];
+          x[j] = dinv[j] * x[j];
+        }
+      }
+    } else if (i != jkf) {
+      t3 += rowdot[i];
     }
     if (i == jkf) {
-      // the reference zeroes the row after the solve (ktensor.h:316-325); its share of term3 goes too
+      // the reference zeroes the row after the solve (ktensor.h:316-325)
 #pragma unroll
       for (int c = 0; c < RM; ++c) x[c] *= 0.0;
     }
@@ -1138,6 +1167,10 @@ __global__ void __launch_bounds__(256) ls_kernel(const LsArgs a) {
         for (long long e = tid; e < n; e += 256) dst[off + e] = src[off + e];
       }
       if (tid < r) a.lambda[col + tid] = a.backup_lambda[col + tid];
+      for (int m = 0; m < a.n_modes; ++m)
+        if (a.act[m])
+          for (int i = tid; i < a.I[m]; i += 256)
+            a.act[m][i + (long long)a.I[m] * col] = a.act_backup[m][i + (long long)a.I[m] * col];
       regram = true;
     }
   }
@@ -1165,6 +1198,10 @@ __global__ void __launch_bounds__(256) ls_kernel(const LsArgs a) {
       for (long long e = tid; e < n; e += 256) dst[off + e] = src[off + e];
     }
     if (tid < r) a.backup_lambda[col + tid] = a.lambda[col + tid];
+    for (int m = 0; m < a.n_modes; ++m)
+      if (a.act[m])
+        for (int i = tid; i < a.I[m]; i += 256)
+          a.act_backup[m][i + (long long)a.I[m] * col] = a.act[m][i + (long long)a.I[m] * col];
     if (tid == 0) {
       a.mt.bk_err[slot] = a.mt.err[slot];
       a.mt.bk_fit[slot] = a.mt.fit[slot];
@@ -1419,12 +1456,12 @@ __global__ void finish_kernel(const FinishArgs a) {
 // per-sweep status of the in-flight models, packed in registry order for ONE device-to-host copy:
 // out[0] = {changed flag of the line search, -, -, -, -}; out[1 + k] = record of slots[k]
 __global__ void pack_status_kernel(const int *slots, int n, ModelTable mt, const int *changed,
-                                   StatusRec *out) {
+                                   const int *nnls_status, StatusRec *out) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k == 0) {
     StatusRec h;
     h.flags = changed ? *changed : 0;
-    h.pad = 0;
+    h.pad = nnls_status ? *nnls_status : 0;
     h.iters = n;
     h.err = h.fit = h.old_fit = 0.0;
     out[0] = h;
@@ -1442,9 +1479,9 @@ __global__ void pack_status_kernel(const int *slots, int n, ModelTable mt, const
 }
 
 hipError_t pack_status_launch(const int *slots, int n, const ModelTable &mt, const int *changed,
-                              StatusRec *out, hipStream_t st) {
+                              const int *nnls_status, StatusRec *out, hipStream_t st) {
   hipLaunchKernelGGL(pack_status_kernel, dim3((std::max(n, 1) + 127) / 128), dim3(128), 0, st, slots, n,
-                     mt, changed, out);
+                     mt, changed, nnls_status, out);
   return hipGetLastError();
 }
 

@@ -36,8 +36,8 @@ enum {
 typedef struct cals_hip_engine cals_hip_engine;
 
 /* The CalsParams fields that steer the loop (include/cals.h:138-159), same names and defaults.
- * update_method is UNCONSTRAINED only; mttkrp_method/mttkrp_lut select among CPU variants in the
- * reference and have no meaning here (one fused kernel family). */
+ * mttkrp_method/mttkrp_lut select among CPU variants in the reference and have no meaning here
+ * (one fused kernel family). */
 typedef struct {
   int64_t max_iterations;   /* 200 */
   double tol;               /* 1e-7 */
@@ -49,6 +49,7 @@ typedef struct {
                              * reference, line_search.cpp:228-283: no step is taken; same here) */
   int force_max_iter;       /* 0 */
   int always_evict_first;   /* 0 */
+  int update_method;        /* update::UPDATE_METHOD (include/utils/update.h:7): 0 UNCONSTRAINED, 1 NNLS */
 } cals_hip_params;
 
 /* CalsReport result fields (include/cals.h:27-63) + device timings (ms) from hipEvents. */
@@ -61,6 +62,9 @@ typedef struct {
   double X_norm;
   double total_ms;          /* whole cals_hip_run call (host clock) */
   double loop_ms;           /* do{}while loop only (host clock, device synchronised) */
+  int nnls_status;          /* NNLS update, OR over all rows since create: 0 clean; 1 a Cholesky failed in
+                             * the main loop (the reference ends on the uncaught CholFail, update.cpp:131);
+                             * 2 a row hit the bound of 4096 set exchanges (the reference has none) */
 } cals_hip_report;
 
 /* Per-model results that the reference keeps inside Ktensor (include/ktensor.h:27-33). */

@@ -56,6 +56,7 @@ void or_default_params(or_params *p) {
   p->force_max_iter = 0;
   p->always_evict_first = 0;
   p->threads = 1;
+  p->update_method = OR_UPDATE_UNCONSTRAINED;
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -364,6 +365,175 @@ int or_update_factor_unconstrained(double *panel, int64_t rows, int64_t r, int64
   return info;
 }
 
+/* ------------------------------------------------------------------------------------------ */
+/* update::update_factor_non_negative_constrained, src/utils/update.cpp:61-176                 */
+/* ------------------------------------------------------------------------------------------ */
+/* calculate_sp, update.cpp:18-48: sp = G[P,P]^-1 y[P] over the passive set P = {i: !active[i]}
+ * through dposv("L") = dpotrf + dpotrs (restated with the oracle's dpotf2 and two substitutions).
+ * Returns the number of passive entries, or -1 when the Cholesky fails (CholFail). */
+static int64_t nnls_calculate_sp(const double *y, double *sp, const double *G, double *Gp,
+                                 const uint8_t *active, int64_t n) {
+  int64_t np = 0;
+  for (int64_t i = 0; i < n; i++) np += !active[i];
+  int64_t a = 0;
+  for (int64_t i = 0; i < n; i++)
+    if (!active[i]) {
+      sp[a] = y[i];
+      int64_t b = 0;
+      for (int64_t j = 0; j < n; j++)
+        if (!active[j]) Gp[a + np * (b++)] = G[i + n * j];
+      a++;
+    }
+  if (np == 0) return 0; /* dposv with n = 0 returns at once */
+  if (dpotf2_lower_ref(Gp, np, np) > 0) return -1;
+  for (int64_t j = 0; j < np; j++) { /* L z = b */
+    double t = sp[j];
+    for (int64_t k = 0; k < j; k++) t -= Gp[j + np * k] * sp[k];
+    sp[j] = t / Gp[j + np * j];
+  }
+  for (int64_t j = np - 1; j >= 0; j--) { /* L^T x = z */
+    double t = sp[j];
+    for (int64_t k = j + 1; k < np; k++) t -= Gp[k + np * j] * sp[k];
+    sp[j] = t / Gp[j + np * j];
+  }
+  return np;
+}
+
+/* Tensor::min() over the np entries sp was resized to (include/tensor.h:260).  With np == 0 the
+ * reference's std::min_element(data, data) returns `data` itself and min() reads the stale sp[0]. */
+static double nnls_min(const double *sp, int64_t np) {
+  double m = sp[0];
+  for (int64_t i = 1; i < np; i++)
+    if (sp[i] < m) m = sp[i];
+  return m;
+}
+
+static void nnls_scatter(double *dst, const double *sp, const uint8_t *active, int64_t n) {
+  int64_t a = 0;
+  for (int64_t i = 0; i < n; i++) dst[i] = active[i] ? 0.0 : sp[a++];
+}
+
+/* calculate_lagrangian_multipliers, update.cpp:50-56: w = y - G d */
+static void nnls_multipliers(const double *y, const double *G, const double *d, double *w,
+                             int64_t n) {
+  for (int64_t i = 0; i < n; i++) w[i] = 0.0;
+  for (int64_t j = 0; j < n; j++) /* dgemv 'N': column sweeps */
+    for (int64_t i = 0; i < n; i++) w[i] += G[i + n * j] * d[j];
+  for (int64_t i = 0; i < n; i++) w[i] = y[i] - w[i];
+}
+
+/* Tensor::max_id(mask), include/tensor.h:232-246: first strictly largest masked entry, 0 if none */
+static int64_t nnls_max_id(const double *w, const uint8_t *mask, int64_t n) {
+  int64_t id = 0;
+  double mx = -DBL_MAX;
+  for (int64_t i = 0; i < n; i++)
+    if (mask[i] && w[i] > mx) {
+      mx = w[i];
+      id = i;
+    }
+  return id;
+}
+
+static int nnls_any(const uint8_t *active, int64_t n, int value) {
+  for (int64_t i = 0; i < n; i++)
+    if ((active[i] != 0) == (value != 0)) return 1;
+  return 0;
+}
+
+/* The reference's loops have no iteration bound (an active-set method ends after finitely many
+ * exchanges in exact arithmetic).  The restatement stops a row after OR_NNLS_MAX_EXCHANGES passes
+ * of either loop and reports it, so that a cycling row cannot hang a test. */
+#define OR_NNLS_MAX_EXCHANGES 4096
+
+/* panel: rows x r (ld) holding the MTTKRP result, overwritten with the constrained solution;
+ * H: r x r (ld r) Hadamard product of the other Gramians (NOT destroyed, unlike the unconstrained
+ * update); active: rows x r flags, row-major [row][i], carried from sweep to sweep
+ * (Ktensor::active_set, include/ktensor.h:37).  Returns 0, 1 when a Cholesky failed in the main
+ * loop (the reference would terminate on the uncaught CholFail), 2 when a row hit the bound. */
+int or_update_factor_nnls(double *panel, int64_t rows, int64_t r, int64_t ld, const double *H,
+                          uint8_t *active_all) {
+  const int64_t n = r;
+  const double eps = 2.2204e-16; /* update.cpp:65 */
+  double one_norm = -DBL_MAX;    /* Matrix::one_norm, include/matrix.h:121-129 */
+  for (int64_t c = 0; c < n; c++) {
+    double s = 0.0;
+    for (int64_t i = 0; i < n; i++) s += fabs(H[i + n * c]);
+    if (s > one_norm) one_norm = s;
+  }
+  const double tol = 10 * eps * one_norm * (double)n;
+  double *y = (double *)xmalloc(sizeof(double) * (size_t)(6 * n + n * n));
+  double *d = y + n, *w = d + n, *s = w + n, *sp = s + n, *Gp = sp + n;
+  int status = 0;
+  for (int64_t i = 0; i < n; i++) sp[i] = 0.0;
+  for (int64_t row = 0; row < rows; row++) {
+    uint8_t *active = active_all + row * n;
+    for (int64_t i = 0; i < n; i++) d[i] = 0.0;
+    for (int64_t i = 0; i < n; i++) {
+      y[i] = panel[row + ld * i];
+      if (y[i] > 0) active[i] = 0;
+    }
+    if (nnls_any(active, n, 0)) { /* warm start from the previous sweep's passive set, :92-121 */
+      int failed = 0;
+      int64_t np = nnls_calculate_sp(y, sp, H, Gp, active, n);
+      if (np < 0) failed = 1;
+      if (!failed) {
+        nnls_scatter(d, sp, active, n);
+        int64_t guard = 0;
+        while (nnls_min(sp, np) <= tol) {
+          for (int64_t i = 0; i < n; i++)
+            if (d[i] <= tol) {
+              d[i] = 0.0;
+              active[i] = 1;
+            }
+          if (!nnls_any(active, n, 0)) { failed = 1; break; } /* ZeroPassiveSet */
+          np = nnls_calculate_sp(y, sp, H, Gp, active, n);
+          if (np < 0) { failed = 1; break; }
+          nnls_scatter(d, sp, active, n);
+          if (++guard > OR_NNLS_MAX_EXCHANGES) { status |= 2; break; }
+        }
+      }
+      if (failed) { /* catch block, :117-120 */
+        for (int64_t i = 0; i < n; i++) active[i] = 1, d[i] = 0.0;
+      }
+    }
+    nnls_multipliers(y, H, d, w, n);
+    int64_t guard = 0;
+    while (nnls_any(active, n, 1) && w[nnls_max_id(w, active, n)] > tol) { /* main loop, :126-167 */
+      const int64_t m = nnls_max_id(w, active, n);
+      active[m] = 0;
+      int64_t np = nnls_calculate_sp(y, sp, H, Gp, active, n);
+      if (np < 0) { status |= 1; break; }
+      int64_t guard2 = 0;
+      while (nnls_min(sp, np) <= tol) { /* inner loop, :136-157 */
+        nnls_scatter(s, sp, active, n);
+        double a = DBL_MAX;
+        for (int64_t i = 0; i < n; i++)
+          if (!active[i] && s[i] <= tol) {
+            const double t = d[i] / (d[i] - s[i]);
+            if (t < a) a = t;
+          }
+        for (int64_t i = 0; i < n; i++) {
+          d[i] = d[i] + a * (s[i] - d[i]);
+          if (fabs(d[i]) < tol && !active[i]) {
+            active[i] = 1;
+            d[i] = 0;
+          }
+        }
+        np = nnls_calculate_sp(y, sp, H, Gp, active, n);
+        if (np < 0) { status |= 1; break; }
+        if (++guard2 > OR_NNLS_MAX_EXCHANGES) { status |= 2; break; }
+      }
+      if (np < 0) break;
+      nnls_scatter(d, sp, active, n);
+      nnls_multipliers(y, H, d, w, n);
+      if (++guard > OR_NNLS_MAX_EXCHANGES) { status |= 2; break; }
+    }
+    for (int64_t i = 0; i < n; i++) panel[row + ld * i] = d[i];
+  }
+  free(y);
+  return status;
+}
+
 /* Ktensor::normalize(mode, iteration), src/ktensor.cpp:66-83 */
 void or_normalize_mode(double *panel, int64_t rows, int64_t r, int64_t ld, double *lambda,
                        int64_t iteration) {
@@ -470,6 +640,7 @@ typedef struct {
   double *fac[OR_MAX_MODES]; /* where the factor currently lives (own storage or buffer view) */
   double *own[OR_MAX_MODES]; /* the storage the Ktensor owns */
   double *lambda;
+  uint8_t *active[OR_MAX_MODES]; /* Ktensor::active_set: [row][i], 1 = constraint active */
   int owns_memory; /* 1 => own[]/lambda were allocated here */
   int64_t iters;
   double fit, old_fit, err;
@@ -487,11 +658,14 @@ static void kt_alloc(kt_t *k, int64_t rank, int n_modes, const int64_t *modes) {
     k->modes[n] = modes[n];
     k->own[n] = (double *)xmalloc(sizeof(double) * (size_t)(modes[n] * rank));
     k->fac[n] = k->own[n];
+    k->active[n] = (uint8_t *)xmalloc((size_t)(modes[n] * rank));
+    memset(k->active[n], 1, (size_t)(modes[n] * rank)); /* include/ktensor.h:69 */
   }
   k->lambda = (double *)xmalloc(sizeof(double) * (size_t)rank);
 }
 
 static void kt_free(kt_t *k) {
+  for (int n = 0; n < k->n_modes; n++) free(k->active[n]);
   if (k->owns_memory) {
     for (int n = 0; n < k->n_modes; n++) free(k->own[n]);
     free(k->lambda);
@@ -507,6 +681,9 @@ static void kt_from_model(kt_t *k, or_model *m, int n_modes, const int64_t *mode
     k->modes[n] = modes[n];
     k->own[n] = m->factors[n];
     k->fac[n] = m->factors[n];
+    /* a freshly constructed Ktensor: every constraint active (include/ktensor.h:69,108) */
+    k->active[n] = (uint8_t *)xmalloc((size_t)(modes[n] * m->rank));
+    memset(k->active[n], 1, (size_t)(modes[n] * m->rank));
   }
   k->lambda = m->lambda;
   k->jk = m->jk_enabled;
@@ -529,8 +706,10 @@ static void kt_copy(kt_t *dst, const kt_t *src) {
   dst->iters = src->iters;
   dst->normalized = src->normalized;
   memcpy(dst->lambda, src->lambda, sizeof(double) * (size_t)src->rank);
-  for (int n = 0; n < src->n_modes; n++)
+  for (int n = 0; n < src->n_modes; n++) {
     memcpy(dst->fac[n], src->fac[n], sizeof(double) * (size_t)(src->modes[n] * src->rank));
+    memcpy(dst->active[n], src->active[n], (size_t)(src->modes[n] * src->rank)); /* :174 */
+  }
 }
 
 /* Ktensor::set_jk_fiber(0.0), include/ktensor.h:316-325 */
@@ -699,6 +878,7 @@ int or_cp_als(const double *X, int n_modes, const int64_t *modes, or_model *mode
   ls_t ls;
   if (prm->line_search) ls_init(&ls, &k, prm, X, X_norm);
   int64_t iter = 0, ls_performed = 0, ls_failed = 0;
+  int nnls_status = 0;
   double t_mttkrp = 0.0;
   k.iters = 0;
   int converged = 0;
@@ -719,7 +899,10 @@ int or_cp_als(const double *X, int n_modes, const int64_t *modes, or_model *mode
       t_mttkrp += now_s() - t0;
       if (n == last) memcpy(G_last, k.fac[n], sizeof(double) * (size_t)(modes[n] * r));
       or_hadamard_but_one(gram, n_modes, r, n);
-      or_update_factor_unconstrained(k.fac[n], modes[n], r, modes[n], gram[n]);
+      if (prm->update_method == OR_UPDATE_UNCONSTRAINED) /* als.cpp:184-187 */
+        or_update_factor_unconstrained(k.fac[n], modes[n], r, modes[n], gram[n]);
+      else
+        nnls_status |= or_update_factor_nnls(k.fac[n], modes[n], r, modes[n], gram[n], k.active[n]);
       if (k.jk && k.jk_mode == n) kt_zero_jk_fiber(&k);
       or_normalize_mode(k.fac[n], modes[n], r, modes[n], k.lambda, k.iters);
       or_update_gramian(k.fac[n], modes[n], r, modes[n], gram[n]);
@@ -756,10 +939,12 @@ int or_cp_als(const double *X, int n_modes, const int64_t *modes, or_model *mode
     rep->total_time = t_end - t_total;
     rep->loop_time = t_end - t_loop;
     rep->mttkrp_time = t_mttkrp;
+    rep->nnls_status = nnls_status;
   }
   if (prm->line_search) ls_free(&ls);
   for (int n = 0; n < n_modes; n++) free(gram[n]);
   free(G_last);
+  kt_free(&k); /* the active sets; the factors belong to the caller */
   return 0;
 }
 
@@ -880,6 +1065,7 @@ static void mkt_remove(mkt_t *m, int64_t id) {
   m->occupancy -= r;
   for (int n = 0; n < m->n_modes; n++) free(e->gram[n]);
   if (e->has_ls) ls_free(&e->ls);
+  kt_free(&e->kt); /* the active sets; the factors belong to the caller */
   free(e);
   memmove(&m->reg[at], &m->reg[at + 1], sizeof(entry_t *) * (size_t)(m->n_reg - at - 1));
   m->n_reg--;
@@ -964,6 +1150,7 @@ int or_cp_cals(const double *X, int n_modes, const int64_t *modes, or_model *mod
 
   int64_t q_head = 0; /* the KtensorQueue: models[q_head..n_models) */
   int64_t sweep = 0, n_kt = 0, comp_sum = 0, ls_performed = 0, ls_failed = 0;
+  int nnls_status = 0;
   double t_mttkrp = 0.0;
   int converged = 0;
   const double t_loop = now_s();
@@ -1000,7 +1187,16 @@ int or_cp_cals(const double *X, int n_modes, const int64_t *modes, or_model *mod
         entry_t *e = m.reg[i];
         const int64_t r = e->kt.rank;
         or_hadamard_but_one(e->gram, n_modes, r, n);
-        or_update_factor_unconstrained(e->kt.fac[n], modes[n], r, modes[n], e->gram[n]);
+        if (prm->update_method == OR_UPDATE_UNCONSTRAINED) /* cals.cpp:244-248 */
+          or_update_factor_unconstrained(e->kt.fac[n], modes[n], r, modes[n], e->gram[n]);
+        else {
+          const int st = or_update_factor_nnls(e->kt.fac[n], modes[n], r, modes[n], e->gram[n],
+                                               e->kt.active[n]);
+          if (st) {
+#pragma omp atomic
+            nnls_status |= st;
+          }
+        }
         if (e->kt.jk && e->kt.jk_mode == n) kt_zero_jk_fiber(&e->kt);
         or_normalize_mode(e->kt.fac[n], modes[n], r, modes[n], e->kt.lambda, e->kt.iters);
         or_update_gramian(e->kt.fac[n], modes[n], r, modes[n], e->gram[n]);
@@ -1069,6 +1265,7 @@ int or_cp_cals(const double *X, int n_modes, const int64_t *modes, or_model *mod
     rep->total_time = t_end - t_total;
     rep->loop_time = t_end - t_loop;
     rep->mttkrp_time = t_mttkrp;
+    rep->nnls_status = nnls_status;
   }
   free(X_norms_jk);
   free(Gn);

@@ -32,6 +32,8 @@ extern "C" {
 enum { OR_MTTKRP = 0, OR_TWOSTEP0 = 1, OR_TWOSTEP1 = 2, OR_AUTO = 3 };
 /* ls::LS_METHOD, include/utils/line_search.h:8 */
 enum { OR_LS_NO_ERROR_CHECKING = 0, OR_LS_ERROR_CHECKING_SERIAL = 1 };
+/* update::UPDATE_METHOD, include/utils/update.h:7 */
+enum { OR_UPDATE_UNCONSTRAINED = 0, OR_UPDATE_NNLS = 1 };
 
 /* CalsParams (include/cals.h:138-159) / AlsParams (include/als.h:142-166), fields on the path. */
 typedef struct {
@@ -46,6 +48,7 @@ typedef struct {
   int force_max_iter;         /* default 0 */
   int always_evict_first;     /* default 0 */
   int threads;                /* what get_threads() would return: drives the AUTO heuristic */
+  int update_method;          /* default OR_UPDATE_UNCONSTRAINED */
 } or_params;
 
 /* CalsReport fields that are results (include/cals.h:27-52). */
@@ -59,6 +62,7 @@ typedef struct {
   double total_time;        /* seconds, whole call */
   double loop_time;         /* seconds, do{}while loop only */
   double mttkrp_time;       /* seconds inside mttkrp() */
+  int nnls_status;          /* OR of or_update_factor_nnls' return values (0 = clean) */
 } or_report;
 
 /* One model (Ktensor, include/ktensor.h:24-44).  Factors are col-major I_n x rank, ld = I_n. */
@@ -98,6 +102,9 @@ void or_mttkrp(const double *X, int n_modes, const int64_t *modes, double *const
 void or_hadamard_but_one(double *const *gramians, int n_modes, int64_t r, int mode);
 void or_hadamard_all(double *const *gramians, int n_modes, int64_t r);
 int or_update_factor_unconstrained(double *panel, int64_t rows, int64_t r, int64_t ld, double *H);
+/* active: rows x r bytes, [row][i], 1 = constraint active; in/out across sweeps */
+int or_update_factor_nnls(double *panel, int64_t rows, int64_t r, int64_t ld, const double *H,
+                          uint8_t *active);
 void or_normalize_mode(double *panel, int64_t rows, int64_t r, int64_t ld, double *lambda,
                        int64_t iteration);
 void or_normalize_all(double *const *factors, int n_modes, const int64_t *modes, int64_t r,

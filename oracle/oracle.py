@@ -14,6 +14,7 @@ _LIB = None
 OR_MAX_MODES = 8
 MTTKRP, TWOSTEP0, TWOSTEP1, AUTO = 0, 1, 2, 3
 LS_NO_ERROR_CHECKING, LS_ERROR_CHECKING_SERIAL = 0, 1
+UNCONSTRAINED, NNLS = 0, 1
 
 
 class OrParams(C.Structure):
@@ -22,6 +23,7 @@ class OrParams(C.Structure):
         ("mttkrp_method", C.c_int), ("line_search", C.c_int), ("line_search_interval", C.c_int),
         ("line_search_step", C.c_double), ("line_search_method", C.c_int),
         ("force_max_iter", C.c_int), ("always_evict_first", C.c_int), ("threads", C.c_int),
+        ("update_method", C.c_int),
     ]
 
 
@@ -30,6 +32,7 @@ class OrReport(C.Structure):
         ("iter", C.c_int64), ("n_ktensors", C.c_int64), ("ktensor_comp_sum", C.c_int64),
         ("ls_performed", C.c_int64), ("ls_failed", C.c_int64), ("X_norm", C.c_double),
         ("total_time", C.c_double), ("loop_time", C.c_double), ("mttkrp_time", C.c_double),
+        ("nnls_status", C.c_int),
     ]
 
 
@@ -169,6 +172,21 @@ def update_step(G_panel, gramians, mode, iteration, jk_fiber=None):
     lib().or_update_gramian(_dp(P), C.c_int64(P.shape[0]), C.c_int64(r), C.c_int64(P.shape[0]),
                             _dp(gs[mode]))
     return P, lam, gs[mode], info
+
+
+def update_factor_nnls(G_panel, H, active=None):
+    """update::update_factor_non_negative_constrained (src/utils/update.cpp:61-176) on one panel.
+    G_panel: rows x r MTTKRP result, H: r x r Hadamard of the other Gramians, active: rows x r uint8
+    (1 = constraint active; None = a fresh Ktensor's all-active sets).
+    Returns (solution rows x r, active rows x r, status)."""
+    P = fcol(G_panel)
+    Hc = fcol(H)
+    rows, r = P.shape
+    act = np.ones((rows, r), dtype=np.uint8) if active is None else np.ascontiguousarray(active, dtype=np.uint8).copy()
+    lib().or_update_factor_nnls.restype = C.c_int
+    st = lib().or_update_factor_nnls(_dp(P), C.c_int64(rows), C.c_int64(r), C.c_int64(rows), _dp(Hc),
+                                     act.ctypes.data_as(C.POINTER(C.c_uint8)))
+    return P, act, int(st)
 
 
 def fast_error(X_norm, lam, last_factor, last_G, gram_had):

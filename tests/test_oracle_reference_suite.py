@@ -2,12 +2,14 @@
 reference ships no golden vectors and cannot be built in this image, see oracle/cals_oracle.h).
 
   tests/als/test_als.cpp:10-60    ComputeCorrectResult3D      -> test_als_variants_agree_3d
+  tests/als/test_als.cpp:62-103   ComputeCorrectResultConstrained3D -> test_als_variants_agree_constrained_3d
   tests/als/test_als.cpp:105-123  ComputeCorrectResult4D      -> test_als_4d
   tests/als/test_als.cpp:125-145  ComputeCorrectError         -> test_fast_error_equals_slow_error
   tests/cals/test_cals.cpp:13-86  SimpleCorrectness           -> test_cals_equals_als
   tests/cals/test_cals.cpp:88-179 LineSearchCorrectness       -> test_cals_equals_als_line_search
   tests/cals/test_cals.cpp:181-297 Jackknifing.LogicCorrectness -> test_jackknife_logic
-(ComputeCorrectResultConstrained3D is the NNLS update, out of scope per SURVEY.md section 8.)
+The NNLS row solver is additionally pinned against SciPy's Lawson-Hanson nnls (an independent
+implementation of the same problem, whose solution is unique for an SPD H).
 Inputs come from the repo's portable generator, not from std::mt19937 (libstdc++-specific).
 """
 import numpy as np
@@ -35,6 +37,50 @@ def test_als_variants_agree_3d(oracle, inputs):
             errs.append(slow)
         for e in errs:
             assert abs(e - errs[0]) <= VARIANT_ACC
+
+
+def test_als_variants_agree_constrained_3d(oracle, inputs):
+    O = oracle
+    modes = [18, 17, 16]
+    X, _, _ = inputs.low_rank_tensor(modes, 5, seed=111)
+    for p in range(20):
+        errs = []
+        for method in (O.MTTKRP, O.TWOSTEP0, O.TWOSTEP1, O.AUTO):
+            (fs, lam, _), = make_models(inputs, modes, [5], seed=300 + p)
+            m = O.Model(fs, lam)
+            prm = O.default_params(max_iterations=100, mttkrp_method=method, update_method=O.NNLS)
+            rep = O.cp_als(X, modes, m, prm)
+            assert rep.nnls_status == 0
+            for f in m.factors:
+                assert (f >= 0.0).all()
+            slow = np.linalg.norm(X - reconstruct(m.factors, m.lam, modes))
+            assert np.isfinite(slow) and slow < 50
+            errs.append(slow)
+        for e in errs:
+            assert abs(e - errs[0]) <= VARIANT_ACC
+
+
+def test_nnls_rows_equal_lawson_hanson(oracle):
+    from scipy.optimize import nnls
+    rng = np.random.default_rng(7)
+    for trial in range(60):
+        r, rows = int(rng.integers(1, 21)), int(rng.integers(1, 24))
+        A = rng.random((rows + r + 5, r)) - (0.5 if trial % 3 == 0 else 0.0)
+        H = A.T @ A
+        Y = np.maximum(rng.standard_normal((rows, r)), 0) @ H + 0.1 * rng.standard_normal((rows, r))
+        P, act, st = oracle.update_factor_nnls(Y, H)
+        assert st == 0
+        L = np.linalg.cholesky(H)
+        for i in range(rows):
+            x, _ = nnls(L.T, np.linalg.solve(L, Y[i]))  # normal equations H x = y
+            assert np.abs(x - P[i]).max() <= 1e-10 * max(1.0, np.abs(x).max())
+            assert ((P[i] == 0) | (act[i] == 0)).all()
+        # warm start from the previous sweep's passive set: same minimiser
+        Y2 = Y + 1e-3 * rng.standard_normal(Y.shape)
+        P2, _, st2 = oracle.update_factor_nnls(Y2, H, act)
+        P3, _, st3 = oracle.update_factor_nnls(Y2, H)
+        assert st2 == 0 and st3 == 0
+        assert np.abs(P2 - P3).max() <= 1e-9 * max(1.0, np.abs(P3).max())
 
 
 def test_als_4d(oracle, inputs):
