@@ -32,7 +32,7 @@
 
 namespace calship {
 
-#define NNLS_MAX_EXCHANGES 4096  // the reference's loops are unbounded; see nnls status bit 2
+#define NNLS_MAX_EXCHANGES 4096  // set exchanges per row; the reference's loops are unbounded (status bit 2)
 
 #define WAVE_SYNC()                                           \
   do {                                                        \
@@ -219,12 +219,12 @@ __global__ void __launch_bounds__(256) nnls_kernel(const NnlsArgs a) {
     unsigned long long act = uniform64(actp[row]) & rmask;
     act &= ~__ballot(in && y > 0.0);  // "determine previous active set" (update.cpp:87-91)
     double d = 0.0, sp = 0.0;
+    int budget = NNLS_MAX_EXCHANGES;
     unsigned long long pas = ~act & rmask;
     if (pas) {  // warm start (update.cpp:93-121)
       bool failed = !solve_passive(Hs, r, ws, pas, __popcll(pas), y, lane, sp);
       if (!failed) {
         d = sp;
-        int guard = 0;
         for (;;) {
           const bool ip = (pas >> lane) & 1ull;
           if (!(wave_min(ip ? sp : DBL_MAX) <= tol)) break;
@@ -241,7 +241,7 @@ __global__ void __launch_bounds__(256) nnls_kernel(const NnlsArgs a) {
             break;
           }
           d = sp;
-          if (++guard > NNLS_MAX_EXCHANGES) {
+          if (--budget <= 0) {
             status |= 2;
             break;
           }
@@ -253,9 +253,8 @@ __global__ void __launch_bounds__(256) nnls_kernel(const NnlsArgs a) {
       }
     }
     double w = multipliers(Hs, r, y, d, lane);
-    int guard = 0;
     for (;;) {  // main loop (update.cpp:126-167)
-      if (!act) break;
+      if (!act || budget <= 0) break;
       const bool ia = (act >> lane) & 1ull;
       const double wmax = wave_max(ia ? w : -DBL_MAX);
       if (!(wmax > tol)) break;
@@ -268,7 +267,6 @@ __global__ void __launch_bounds__(256) nnls_kernel(const NnlsArgs a) {
         break;
       }
       bool stop = false;
-      int guard2 = 0;
       for (;;) {  // inner loop (update.cpp:136-157)
         const bool ip = (pas >> lane) & 1ull;
         if (!(wave_min(ip ? sp : DBL_MAX) <= tol)) break;
@@ -288,7 +286,7 @@ __global__ void __launch_bounds__(256) nnls_kernel(const NnlsArgs a) {
           stop = true;
           break;
         }
-        if (++guard2 > NNLS_MAX_EXCHANGES) {
+        if (--budget <= 0) {
           status |= 2;
           break;
         }
@@ -296,7 +294,7 @@ __global__ void __launch_bounds__(256) nnls_kernel(const NnlsArgs a) {
       if (stop) break;
       d = sp;
       w = multipliers(Hs, r, y, d, lane);
-      if (++guard > NNLS_MAX_EXCHANGES) {
+      if (--budget <= 0) {
         status |= 2;
         break;
       }
