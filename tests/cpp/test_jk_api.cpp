@@ -171,6 +171,30 @@ int main() {
     }
   }
   printf("cp_omp_als vs cp_als: worst factor entry difference = %.3e\n", worst_omp);
+  // tests/als/test_als.cpp:62-103 (ComputeCorrectResultConstrained3D) through the C++ API:
+  // update::NNLS gives non-negative factors and a finite reconstruction error equal to the fast one
+  double worst_neg = 0.0, nnls_err_gap = 0.0;
+  {
+    cals::AlsParams np = ap;
+    np.update_method = cals::update::UPDATE_METHOD::NNLS;
+    np.max_iterations = 100;
+    cals::Ktensor k(5, modes);
+    k.fill([]() { return 0.5 * (next_pm1() + 1.0); });
+    cals::cp_als(T, k, np);
+    for (int n = 0; n < 3; n++) {
+      const auto &f = k.get_factor(n);
+      for (dim_t e = 0; e < f.get_n_elements(); e++)
+        if (!(f.get_data()[e] >= -worst_neg)) worst_neg = -f.get_data()[e];
+    }
+    cals::Tensor a = k.to_tensor();
+    double d = 0.0;
+    for (dim_t e = 0; e < a.get_n_elements(); e++) d += (T[e] - a[e]) * (T[e] - a[e]);
+    d = std::sqrt(d);
+    nnls_err_gap = std::fabs(d - k.get_approximation_error());
+    if (!std::isfinite(d) || std::isnan(worst_neg)) worst_neg = 1.0;
+  }
+  printf("cp_als with update::NNLS: most negative entry = %.3e, |slow - fast error| = %.3e\n", worst_neg,
+         nnls_err_gap);
   // source-compatibility members the front-ends use (include/ktensor.h:161-170, utils/mttkrp.h:100,
   // extern/rectangular_lsap/rectangular_lsap.h:44)
   {
@@ -187,5 +211,5 @@ int main() {
     for (int i = 0; i < 3; i++) tot += cost[ra[i] * 3 + cb[i]];
     if (tot != 5.0) return 6;
   }
-  return (worst <= 1e-9 && worst_als <= 1e-8 && worst_omp <= 1e-10) ? 0 : 1;
+  return (worst <= 1e-9 && worst_als <= 1e-8 && worst_omp <= 1e-10 && worst_neg == 0.0 && nnls_err_gap <= 1e-8) ? 0 : 1;
 }
