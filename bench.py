@@ -28,7 +28,12 @@ WORKLOADS = {
     "c1": ([20, 20, 20], 4, 0),        # BASELINE config 1 (plumbing)
     "c4": ([299, 301, 41], 512, 0),    # BASELINE config 4: eemdata-shaped, fp32 storage + fp32 MFMA
     "c4f64": ([299, 301, 41], 512, 0),  # config 4's shape and model count, in fp64
+    # BASELINE config 5: 2048 models IN TOTAL sharded round-robin over the N GPUs (strong scaling:
+    # a step = one sweep of all 2048 models; value = steps / max time).  N = 1 gives the denominator of
+    # north_star's ">= 6x at 8 GPUs".
+    "c5": ([300, 300, 300], 2048, 1),
 }
+STRONG = {"c5"}
 WORKLOAD_DTYPE = {"c4": "f32"}
 PEAK_FP32_MFMA_TFLOPS = 157.3  # dense FP32 matrix peak (v_mfma_f32_16x16x4_f32: 256 flop/cycle/CU x4 SIMD)
 PEAK_FP64_MFMA_TFLOPS = 78.6  # MI355X dense FP64 matrix peak (datasheet; 256 CU x 4 SIMD x 2.4 GHz
@@ -119,7 +124,15 @@ def main():
     red_dev = dev if (world == 1 or args.dist_backend == "nccl") else torch.device("cpu")
 
     modes, k_models, ls = WORKLOADS[args.workload]
-    ranks = local_ranks(k_models)           # this rank's shard: models m = rank + world*k
+    strong = args.workload in STRONG
+    if strong:
+        total_models = k_models
+        mine = list(range(rank, total_models, world))   # model m -> GPU m mod N
+        k_models = len(mine)
+        ranks = [1 + (m % 20) for m in mine]
+    else:
+        total_models = k_models * world
+        ranks = local_ranks(k_models)       # this rank's shard: models m = rank + world*k
     R = sum(ranks)
     X = inputs.tensor(modes, seed=0)        # replicated: every rank generates the same X
     base = inputs.model_factors(modes, ranks, seed=1 + rank)
@@ -149,6 +162,8 @@ def main():
     elapsed = time.perf_counter() - t0
 
     value, t_max = sharding.aggregate_rate(args.steps, elapsed, device=red_dev)
+    if strong:
+        value = args.steps / t_max          # one step advances the WHOLE job by one sweep
     ks = eng.kernel_stats()
     plan = eng.tree
     eng.set_profiling(False)
@@ -186,14 +201,17 @@ def main():
             "metric": "ALS iterations/sec (all concurrent models)",
             "value": round(value, 3), "unit": "ALS it/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(t_max / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype,
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": dtype,
             "data": "synthetic",
-            "config": {"workload": "%s %s dense tensor, %d concurrent CP models per GPU, ranks 1..20 "
-                                   "(R=%d columns), line search %s; one step = one ALS sweep of a GPU's "
-                                   "model shard; value = sweeps by all %d GPU(s) / max time" % (
-                                       "x".join(map(str, modes)), "fp32" if dtype == "f32" else "fp64",
-                                       k_models, R, "on" if ls else "off", world),
-                       "name": args.workload, "models_per_gpu": k_models, "total_models": k_models * world,
+            "config": {"workload": ("%s %s dense tensor, %d concurrent CP models per GPU, ranks 1..20 "
+                                    "(R=%d columns), line search %s; " % (
+                                        "x".join(map(str, modes)), "fp32" if dtype == "f32" else "fp64",
+                                        k_models, R, "on" if ls else "off")) + (
+                                    "one step = one ALS sweep of ALL %d models (sharded over %d GPU(s)); "
+                                    "value = steps / max time" % (total_models, world) if strong else
+                                    "one step = one ALS sweep of a GPU's model shard; value = sweeps by all "
+                                    "%d GPU(s) / max time" % world),
+                       "name": args.workload, "models_per_gpu": k_models, "total_models": total_models,
                        "sharding": "model m -> GPU m mod N, X replicated, no data-path collective"},
             "roofline": {"bound": "mfma", "kernel": "%s, v_mfma_%s" % (
                              dom, "f32_16x16x4_f32" if dtype == "f32" else "f64_16x16x4_f64"),
@@ -209,7 +227,7 @@ def main():
                          "other_kernels_ms_per_step": round((ks.update_ms + ks.other_ms) / args.steps, 4)},
         }
     eng.close()
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not strong:
         threads = args.cpu_threads or min(len(os.sched_getaffinity(0)), 16)
         out["cpu_baseline"] = cpu_baseline(modes, ranks, X, base, ls, threads, args.cpu_sweeps)
     elif rank == 0:

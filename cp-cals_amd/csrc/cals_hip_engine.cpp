@@ -345,6 +345,35 @@ int alloc_nnls(cals_hip_engine *e) {
 struct Geo {
   int NB, T;
 };
+// Team size (workgroups that split the streamed range of one column block) for `wg_per_member`
+// x NB x T workgroups of equal work on n_cu CUs: the chip runs them in ceil(grid / n_cu) rounds of
+// ceil(units / T) + overhead each.  One round (grid <= n_cu) is best while NB divides the chip
+// well (C3: 21 column blocks x 12 = 252 of 256 CUs); with many column blocks (2048 models: NB = 168)
+// a single round would leave a third of the CUs idle, so the range is cut finer and the hardware's
+// dispatcher balances several rounds.  Among team sizes within 2 % of the best estimate the largest
+// is taken (more members per column block = fewer distinct P panels live in an XCD's L2 at a time).
+long long pick_team(long long nb_wgs, long long units, long long overhead, int n_cu, long long t_cap) {
+  t_cap = std::max<long long>(1, std::min(t_cap, units));
+  double best = 1e300;
+  for (long long T = 1; T <= t_cap; T++) {
+    const long long rounds = (nb_wgs * T + n_cu - 1) / n_cu;
+    const double cost = (double)rounds * (double)((units + T - 1) / T + overhead);
+    best = std::min(best, cost);
+  }
+  long long pick = 1;
+  for (long long T = 1; T <= t_cap; T++) {
+    const long long rounds = (nb_wgs * T + n_cu - 1) / n_cu;
+    const double cost = (double)rounds * (double)((units + T - 1) / T + overhead);
+    if (cost <= best * 1.02) pick = T;
+  }
+  return pick;
+}
+
+// partial tiles the MTTKRP kernels may write (sizes e->partial)
+size_t partial_tile_cap(const cals_hip_engine *e, size_t nb_max) {
+  return std::max<size_t>((size_t)8 * e->n_cu, nb_max);
+}
+
 Geo geometry(const cals_hip_engine *e, int mode, int64_t R) {
   const ModeLayout &L = e->lay[mode];
   Geo g;
@@ -355,6 +384,13 @@ Geo geometry(const cals_hip_engine *e, int mode, int64_t R) {
                                           : e->n_cu / std::max(1, g.NB * L.m_blocks);
   if (T < 1) T = 1;
   if (T > U) T = U;
+  if (e->mttkrp_kernel == 4 && (long long)g.NB * L.m_blocks > e->n_cu / 2) {
+    // many column blocks: several rounds of finer workgroups (see pick_team); unit = 16 rows of the
+    // inner mode for one s, overhead ~ 1 % of a column block's units
+    const size_t nb_max = (size_t)((e->buffer + CALS_BN - 1) / CALS_BN);
+    T = pick_team((long long)g.NB * L.m_blocks, U, std::max<long long>(1, U / 100), e->n_cu,
+                  (long long)(partial_tile_cap(e, nb_max) / ((size_t)g.NB * L.m_blocks)));
+  }
   g.T = (int)T;
   return g;
 }
@@ -433,6 +469,15 @@ int launch_mttkrp(cals_hip_engine *e, int mode, int64_t R, Geo *geo_out, void *c
   return CALS_HIP_OK;
 }
 
+// column blocks per locality group of the TTM: their P panels take <= 2 MB of an XCD's 4 MB L2
+// (CALS_TTM_NBW overrides)
+long long ttm_nbw(const cals_hip_engine *e, int first) {
+  const size_t panel = (size_t)e->lay[first].Ap * CALS_BN * e->es;
+  long long nbw = (long long)((2u << 20) / std::max<size_t>(panel, 1));
+  if (const char *v = getenv("CALS_TTM_NBW")) nbw = atoi(v);
+  return std::max<long long>(nbw, 1);
+}
+
 // TTM of pair[first]: T = X x_a P (to HBM) and the partial tiles of G_first
 Geo tree_geometry(const cals_hip_engine *e, int first, int64_t R) {
   const PairCfg &pc = e->tree.pair[first];
@@ -440,9 +485,33 @@ Geo tree_geometry(const cals_hip_engine *e, int first, int64_t R) {
   Geo g;
   g.NB = (int)((R + CALS_BN - 1) / CALS_BN);
   (void)pc;  // a workgroup walks all M blocks of the pair: the team splits s only
-  long long T = e->n_cu / std::max(1, g.NB);
-  if (T < 1) T = 1;
-  if (T > e->modes[second]) T = e->modes[second];
+  // unit = one s (all M blocks of it); overhead (pipeline fill + the partial G tile) ~ half a unit:
+  // cost = rounds * (2 * ceil(S / T) + 1).  One round while NB divides the chip well (C3: 21 x 12 =
+  // 252 workgroups on 256 CUs); with many column blocks (2048 models: NB = 168, where one round
+  // would leave a third of the CUs idle) the s range is cut finer and the dispatcher balances
+  // several rounds.  Among the team sizes within 2 % of the best estimate: the smallest that still
+  // keeps an XCD's 32 concurrent workgroups inside one locality group of P panels (T * nbw >= 32),
+  // else the largest.
+  const size_t nb_max = (size_t)((e->buffer + CALS_BN - 1) / CALS_BN);
+  long long T = 1;
+  {
+    const long long S = e->modes[second];
+    const long long cap = std::max<long long>(1, std::min<long long>(S, (long long)(partial_tile_cap(e, nb_max) / (size_t)g.NB)));
+    const long long nbw = std::max<long long>(1, std::min<long long>(ttm_nbw(e, first), g.NB));
+    auto cost = [&](long long t) {
+      const long long rounds = ((long long)g.NB * t + e->n_cu - 1) / e->n_cu;
+      return (double)rounds * (double)(2 * ((S + t - 1) / t) + 1);
+    };
+    double best = 1e300;
+    for (long long t = 1; t <= cap; t++) best = std::min(best, cost(t));
+    long long largest = 1, local = 0;
+    for (long long t = 1; t <= cap; t++)
+      if (cost(t) <= best * 1.02) {
+        largest = t;
+        if (!local && t * nbw >= 32) local = t;
+      }
+    T = local ? local : largest;
+  }
   static const int forced_t = getenv("CALS_TTM_TEAMS") ? atoi(getenv("CALS_TTM_TEAMS")) : 0;  // experiments
   if (forced_t > 0) T = std::min<long long>(forced_t, e->modes[second]);
   g.T = (int)T;
@@ -478,13 +547,7 @@ int launch_ttm(cals_hip_engine *e, int first, int64_t R, Geo *geo_out) {
   a.T = g.T;
   a.ldPart = L.ldPart;
   a.grid = g.NB * g.T;
-  {
-    // P panels of one locality group: <= 2 MB of an XCD's 4 MB L2 (CALS_TTM_NBW overrides)
-    const size_t panel = (size_t)L.Ap * CALS_BN * e->es;
-    long long nbw = (long long)((2u << 20) / std::max<size_t>(panel, 1));
-    if (const char *v = getenv("CALS_TTM_NBW")) nbw = atoi(v);
-    a.nbw = (int)std::min<long long>(std::max<long long>(nbw, 1), g.NB);
-  }
+  a.nbw = (int)std::min<long long>(ttm_nbw(e, first), g.NB);
   a.m_blocks = pc.m_blocks;
   a.k_big = pc.k_big;
   a.MT = pc.MT;
@@ -1145,7 +1208,7 @@ int cals_hip_create_ex(cals_hip_engine **out, int n_modes, const int64_t *modes,
   }
   size_t ld_max = 0;
   for (int n = 0; n < n_modes; n++) ld_max = std::max<size_t>(ld_max, (size_t)e->lay[n].ldPart);
-  e->partial_elems = std::max<size_t>((size_t)2 * e->n_cu, nb_max) * ld_max * CALS_BN;
+  e->partial_elems = partial_tile_cap(e, nb_max) * ld_max * CALS_BN;
   if (getenv("CALS_TTM_TRACE")) {
     if ((rc = dev_alloc(e, &e->dbg_trace, (size_t)16 * 2048))) return rc;
   }
