@@ -150,7 +150,7 @@ def main():
 
     eng.sweep(args.warmup)
     eng.synchronize()
-    eng.set_profiling(True)
+    eng.set_profiling(2)                    # hipEvent pairs around the MFMA kernels + the contraction only
     eng.reset_kernel_stats()
 
     sharding.barrier()
@@ -224,7 +224,8 @@ def main():
                                   3: "multi-sweep dimension tree (every TTM shared by two consecutive "
                                      "updates: 3 TTMs per 2 sweeps)"}[plan],
                          "mfma_kernels": kern, "contract_kernel": contract,
-                         "other_kernels_ms_per_step": round((ks.update_ms + ks.other_ms) / args.steps, 4)},
+                         "rest_ms_per_step": round(
+                             t_max / args.steps * 1e3 - (ks.mttkrp_ms + ks.ttm_ms + ks.contract_ms) / args.steps, 4)},
         }
     eng.close()
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not strong:

@@ -338,8 +338,9 @@ class Engine:
         self._chk(self.lib.cals_hip_debug_get_norms(self.h, C.byref(xn), _dp(jk)))
         return xn.value, jk
 
-    def set_profiling(self, on):
-        self._chk(self.lib.cals_hip_set_profiling(self.h, 1 if on else 0))
+    def set_profiling(self, level):
+        """0/False off, 1/True every launch, 2 MFMA kernels + contraction only (cheaper, see cals_hip.h)."""
+        self._chk(self.lib.cals_hip_set_profiling(self.h, int(level)))
 
     def kernel_stats(self):
         ks = KernelStats()

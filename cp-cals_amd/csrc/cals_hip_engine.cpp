@@ -148,7 +148,7 @@ struct cals_hip_engine {
   int64_t n_ktensors = 0, comp_sum = 0, ls_performed = 0, ls_failed = 0, sweeps = 0;
 
   // profiling
-  bool profiling = false;
+  int profiling = 0;  // 0 off, 1 every launch, 2 MFMA kernels + contraction only
   std::vector<EventPair> ev_pool;
   size_t ev_used = 0;
   struct Rec {
@@ -248,6 +248,10 @@ void compress_plan(const int64_t *occ, int64_t n, std::vector<std::pair<int64_t,
 // ---- profiling helpers ----
 int prof_begin(cals_hip_engine *e, int cls, double flops) {
   if (!e->profiling) return -1;
+  // level 2: only the MFMA kernels and the contraction (classes 0, 3, 4).  An event pair is two more
+  // packets on the queue and keeps the next launch from overlapping the kernel's tail: around all 13
+  // launches of a sweep that costs 62 us per sweep (23 % at C2, 1.9 % at C3; tools/profiling_cost.py).
+  if (e->profiling == 2 && (cls == 1 || cls == 2)) return -1;
   if (e->ev_used >= e->ev_pool.size()) {
     if (e->ev_pool.size() >= 16384) return -1;
     EventPair p;
@@ -1683,7 +1687,7 @@ int cals_hip_debug_get_norms(cals_hip_engine *e, double *X_norm, double *jk_norm
 int cals_hip_set_profiling(cals_hip_engine *e, int enabled) {
   if (!e) return CALS_HIP_ERR_ARG;
   if (!enabled) prof_collect(e);
-  e->profiling = enabled != 0;
+  e->profiling = enabled < 0 ? 0 : (enabled > 2 ? 2 : enabled);
   return CALS_HIP_OK;
 }
 

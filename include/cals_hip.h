@@ -208,7 +208,10 @@ int64_t cals_hip_host_compress_plan(const int64_t *occupancy, int64_t n_cols, in
 int64_t cals_hip_host_active_cols(const int64_t *occupancy, int64_t n_cols);
 
 /* ---- measurement ---- */
-int cals_hip_set_profiling(cals_hip_engine *e, int enabled);
+/* level: 0 off; 1 hipEvent pairs around every launch; 2 around the MFMA kernels (MTTKRP, TTM) and the
+ * contraction only -- the pairs themselves cost ~5 us per launch of queue time, which matters when a
+ * sweep is 13 launches of 4-40 us (BASELINE config 2). */
+int cals_hip_set_profiling(cals_hip_engine *e, int level);
 int cals_hip_get_kernel_stats(cals_hip_engine *e, cals_hip_kernel_stats *out);
 int cals_hip_reset_kernel_stats(cals_hip_engine *e);
 /* hipStream_t the engine launches on (as void*), so callers can bracket it with their own events */
