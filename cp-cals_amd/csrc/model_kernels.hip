@@ -485,47 +485,51 @@ __device__ __attribute__((noinline)) void update_body_lds(const UpdateArgs &a, i
   // NNLS update: the panel already holds the constrained solution (nnls_kernel.hip)
   const double *rowdot = a.rowdot ? a.rowdot + (long long)I * blockIdx.x : nullptr;
   const bool solved = rowdot != nullptr;
-  // dpotrf('L') restated as unblocked dpotf2 on wave 0 (lane = row).  info != 0: stop, keep going
-  // with whatever is in H, as the reference does (update.cpp:183-185 only logs).
+  // dpotrf('L') restated as unblocked dpotf2 on wave 0, lane = row, the row held in REGISTERS: the
+  // entries L[j][k] that the column update needs from row j come through v_readlane (j and k are
+  // compile-time after unrolling), so the factorisation touches LDS only to load H and to store L.
+  // (With the rows in LDS every column cost two dependent LDS round trips per 4 k: 22.9 K of the
+  // kernel's 64 K cycles at rank 20.)  Same operations in the same order as before: for column j,
+  // s_i = H[i][j] - L[i][0] L[j][0] - ... - L[i][j-1] L[j][j-1] for every row i >= j; ajj = s_j.
+  // info != 0: stop, keep going with whatever is in H, as the reference does (update.cpp:183-185
+  // only logs).
   if (wave == 0 && !solved) {
+    double Lr[RMAX];
+    const int li = lane < r ? lane : 0;
+#pragma unroll
+    for (int c = 0; c < RMAX; ++c) Lr[c] = (c < r) ? Hs[li + RMAX * c] : 0.0;
     int info = 0;
-    for (int j = 0; j < r; ++j) {
-      const bool below = lane > j && lane < r;
-      double ajj = Hs[j + RMAX * j];
-      double sv = below ? Hs[lane + RMAX * j] : 0.0;
-      const int lrow = below ? lane : j;  // lanes outside the column read row j again (unused)
-      int k = 0;
-      for (; k + 4 <= j; k += 4) {  // four load pairs in flight; the subtractions stay in k order
-        const double l0 = Hs[j + RMAX * k], l1 = Hs[j + RMAX * (k + 1)];
-        const double l2 = Hs[j + RMAX * (k + 2)], l3 = Hs[j + RMAX * (k + 3)];
-        const double m0 = Hs[lrow + RMAX * k], m1 = Hs[lrow + RMAX * (k + 1)];
-        const double m2 = Hs[lrow + RMAX * (k + 2)], m3 = Hs[lrow + RMAX * (k + 3)];
-        ajj -= l0 * l0;
-        ajj -= l1 * l1;
-        ajj -= l2 * l2;
-        ajj -= l3 * l3;
-        sv -= m0 * l0;
-        sv -= m1 * l1;
-        sv -= m2 * l2;
-        sv -= m3 * l3;
+#pragma unroll
+    for (int j = 0; j < RMAX; ++j) {
+      if (j < r && info == 0) {
+        double sv = Lr[j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) {
+          const double ljk = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(Lr[k]), j),
+                                              __builtin_amdgcn_readlane(__double2loint(Lr[k]), j));
+          sv -= Lr[k] * ljk;
+        }
+        const double ajj = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(sv), j),
+                                            __builtin_amdgcn_readlane(__double2loint(sv), j));
+        if (!(ajj > 0.0)) {
+          if (lane == j) Lr[j] = ajj;
+          info = j + 1;
+        } else {
+          const double ljj = sqrt(ajj);
+          if (lane == j)
+            Lr[j] = ljj;
+          else if (lane > j)
+            Lr[j] = sv / ljj;
+        }
       }
-      for (; k < j; ++k) {
-        const double ljk = Hs[j + RMAX * k];
-        ajj -= ljk * ljk;
-        sv -= Hs[lrow + RMAX * k] * ljk;
-      }
-      if (!(ajj > 0.0)) {
-        if (lane == 0) Hs[j + RMAX * j] = ajj;
-        info = j + 1;
-        break;
-      }
-      ajj = sqrt(ajj);
-      if (lane == j)
-        Hs[j + RMAX * j] = ajj;
-      else if (below)
-        Hs[lane + RMAX * j] = sv / ajj;
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     }
+    if (lane < r) {
+#pragma unroll
+      for (int c = 0; c < RMAX; ++c)
+        if (c <= lane && c < r) Hs[lane + RMAX * c] = Lr[c];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
     if (lane < r) sh.dinv[lane] = 1.0 / Hs[lane + RMAX * lane];
     if (lane == 0) a.mt.potrf_info[slot] = info;
   }

@@ -153,6 +153,36 @@ def test_nnls_f32_storage(cc, oracle, inputs):
         assert TOL32_FIT > 0
 
 
+def test_nnls_golden(cc, inputs):
+    """The committed vectors of tests/golden/nnls_18x17x16.npz (oracle output, make_golden.py) at 1, 2 and 20
+    forced sweeps."""
+    import importlib.util
+    import os
+    gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(gdir, "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    case = mg.CASES["nnls_18x17x16"]
+    gold = np.load(os.path.join(gdir, "nnls_18x17x16.npz"))
+    modes, ranks = case["modes"], case["ranks"]
+    X = mg.tensor_of(case)
+    for it in case["iters"]:
+        base = make_models(inputs, modes, ranks, seed=case["mseed"])
+        e = cc.Engine(modes, sum(ranks))
+        e.set_tensor(X)
+        e.set_params(cc.default_params(max_iterations=it, force_max_iter=1, update_method=NNLS))
+        gm = [cc.Model([f.copy() for f in fs], lam.copy()) for fs, lam, _ in base]
+        for m in gm:
+            e.enqueue(m)
+        rep = e.run()
+        e.close()
+        assert rep.iter == gold["it%d_sweeps" % it][0] and rep.nnls_status == 0
+        for n in range(3):
+            assert rel(np.hstack([m.factors[n] for m in gm]), gold["it%d_factor%d" % (it, n)]) < TOL_NNLS
+        assert rel(np.concatenate([m.lam for m in gm]), gold["it%d_lambda" % it]) < TOL_NNLS
+        assert np.allclose([m.error for m in gm], gold["it%d_error" % it], rtol=1e-9, atol=1e-12)
+
+
 def test_nnls_slow_error_equals_fast_error(cc, inputs):
     """ComputeCorrectResultConstrained3D's checks on the device result: non-negative factors, finite
     reconstruction error, and the error formula's value equals the reconstructed one."""
