@@ -17,6 +17,7 @@
 #include <cstring>
 #include <deque>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 using namespace calship;
@@ -114,6 +115,13 @@ struct cals_hip_engine {
   int *d_nnls_status = nullptr;
   int nnls_status = 0;
   bool nnls_allocated = false, nnls_ls_allocated = false;
+  // batched column traffic (eviction, compress): device scratch + index lists, pinned host staging
+  unsigned *col_scratch = nullptr;
+  size_t col_scratch_words = 0;
+  int *d_colidx = nullptr;
+  size_t colidx_cap = 0;
+  unsigned *h_stage = nullptr;
+  size_t h_stage_words = 0;
   void *partial = nullptr;
   size_t partial_elems = 0;
   void *krp_ws = nullptr;
@@ -791,45 +799,83 @@ int fetch_status(cals_hip_engine *e) {
 
 // MultiKtensor::remove + Ktensor::detach (multi_ktensor.cpp:132-163, ktensor.cpp:127-135):
 // copy the models' columns back to the callers, zero them on the device, free the columns.
+// device scratch for n_cols columns of `words_per_col` 4-byte words in total, index lists of n_idx ints
+int ensure_col_scratch(cals_hip_engine *e, size_t words, size_t n_idx, bool host_too) {
+  if (words > e->col_scratch_words) {
+    if (e->col_scratch) HIPCHK(hipFree(e->col_scratch));
+    e->col_scratch = nullptr;
+    e->col_scratch_words = words + words / 2;
+    HIPCHK(hipMalloc((void **)&e->col_scratch, e->col_scratch_words * sizeof(unsigned)));
+  }
+  if (n_idx > e->colidx_cap) {
+    if (e->d_colidx) HIPCHK(hipFree(e->d_colidx));
+    e->d_colidx = nullptr;
+    e->colidx_cap = std::max<size_t>(2 * n_idx, 4096);
+    HIPCHK(hipMalloc((void **)&e->d_colidx, e->colidx_cap * sizeof(int)));
+  }
+  if (host_too && words > e->h_stage_words) {
+    if (e->h_stage) HIPCHK(hipHostFree(e->h_stage));
+    e->h_stage = nullptr;
+    e->h_stage_words = words + words / 2;
+    HIPCHK(hipHostMalloc((void **)&e->h_stage, e->h_stage_words * sizeof(unsigned), hipHostMallocDefault));
+  }
+  return CALS_HIP_OK;
+}
+
 int remove_models(cals_hip_engine *e, std::vector<int64_t> rm) {
   if (rm.empty()) return CALS_HIP_OK;
-  // Ktensor::detach for every evicted model: models in adjacent columns come back as ONE D2H per
-  // mode (staging buffer, then scattered into the callers' storage) and one memset per mode.
+  // Ktensor::detach for every evicted model, all of them at once: ONE gather kernel packs their
+  // columns of every factor (zeroing the source, multi_ktensor.cpp:148-150) and of lambda into a
+  // compact device buffer, ONE D2H brings it to pinned host memory, the host scatters it into the
+  // callers' storage.
   std::sort(rm.begin(), rm.end(),
             [&](int64_t a, int64_t b) { return e->models[a].col < e->models[b].col; });
-  std::vector<double> stage;
-  std::vector<float> stage_f;
-  size_t k0 = 0;
-  while (k0 < rm.size()) {
-    size_t k1 = k0 + 1;
-    int64_t cols = e->models[rm[k0]].rank;
-    while (k1 < rm.size() && e->models[rm[k1]].col == e->models[rm[k0]].col + cols) {
-      cols += e->models[rm[k1]].rank;
-      k1++;
-    }
-    const int64_t col0 = e->models[rm[k0]].col;
-    for (int n = 0; n <= e->n_modes; n++) {  // n == n_modes: lambda
-      const int64_t rows = (n < e->n_modes) ? e->modes[n] : 1;
-      stage.resize((size_t)(rows * cols));
-      const bool f32 = (n < e->n_modes) && e->dtype == CALS_F32;
-      if (f32) stage_f.resize(stage.size());
-      void *src = (n < e->n_modes) ? elem_ptr(e, e->factor[n], rows * col0) : (void *)(e->lambda + col0);
-      const size_t bytes = stage.size() * (f32 ? sizeof(float) : sizeof(double));
-      HIPCHK(hipMemcpyAsync(f32 ? (void *)stage_f.data() : (void *)stage.data(), src, bytes,
-                            hipMemcpyDeviceToHost, e->stream));
-      if (n < e->n_modes) HIPCHK(hipMemsetAsync(src, 0, bytes, e->stream));
-      HIPCHK(hipStreamSynchronize(e->stream));
-      if (f32)
-        for (size_t i = 0; i < stage.size(); i++) stage[i] = (double)stage_f[i];
-      size_t off = 0;
-      for (size_t k = k0; k < k1; k++) {
-        HostModel &m = e->models[rm[k]];
-        double *dst = (n < e->n_modes) ? m.factors[n] : m.lambda;
-        std::memcpy(dst, stage.data() + off, sizeof(double) * (size_t)(rows * m.rank));
-        off += (size_t)(rows * m.rank);
+  std::vector<int> cols;
+  for (auto t : rm) {
+    const HostModel &m = e->models[t];
+    for (int64_t c = 0; c < m.rank; c++) cols.push_back((int)(m.col + c));
+  }
+  const size_t nc = cols.size();
+  const int wpe = (e->dtype == CALS_F32) ? 1 : 2;
+  ColMoveArgs a{};
+  size_t words = 0;
+  for (int n = 0; n < e->n_modes; n++) {
+    a.buf[n] = ColBuf{e->factor[n], (long long)e->modes[n], wpe};
+    a.scratch_off[n] = (long long)words;
+    words += (size_t)e->modes[n] * wpe * nc;
+  }
+  a.buf[e->n_modes] = ColBuf{e->lambda, 1, 2};
+  a.scratch_off[e->n_modes] = (long long)words;
+  words += 2 * nc;
+  a.n_bufs = e->n_modes + 1;
+  a.zero_src_bufs = e->n_modes;  // lambda is left as it is, as before
+  int rc = ensure_col_scratch(e, words, nc, true);
+  if (rc) return rc;
+  HIPCHK(hipMemcpyAsync(e->d_colidx, cols.data(), nc * sizeof(int), hipMemcpyHostToDevice, e->stream));
+  a.src = e->d_colidx;
+  a.dst = e->d_colidx;
+  a.n_cols = (int)nc;
+  a.scratch = e->col_scratch;
+  HIPCHK(gather_columns_launch(a, e->stream));
+  HIPCHK(hipMemcpyAsync(e->h_stage, e->col_scratch, words * sizeof(unsigned), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  {
+    size_t k0 = 0;  // first staged column of the model
+    for (auto t : rm) {
+      HostModel &m = e->models[t];
+      for (int n = 0; n < e->n_modes; n++) {
+        const size_t cnt = (size_t)(e->modes[n] * m.rank);
+        const unsigned *src = e->h_stage + a.scratch_off[n] + (size_t)e->modes[n] * wpe * k0;
+        if (e->dtype == CALS_F32) {
+          const float *f = reinterpret_cast<const float *>(src);
+          for (size_t i = 0; i < cnt; i++) m.factors[n][i] = (double)f[i];
+        } else {
+          std::memcpy(m.factors[n], src, cnt * sizeof(double));
+        }
       }
+      std::memcpy(m.lambda, e->h_stage + a.scratch_off[e->n_modes] + 2 * k0, sizeof(double) * (size_t)m.rank);
+      k0 += (size_t)m.rank;
     }
-    k0 = k1;
   }
   for (auto ticket : rm) {
     HostModel &m = e->models[ticket];
@@ -858,36 +904,66 @@ int compress(cals_hip_engine *e) {
     return CALS_HIP_OK;
   }
   tree_invalidate(e);
+  // host bookkeeping request by request (as the reference applies them, left to right); the column
+  // traffic of ALL requests and ALL buffers then goes out as one gather + one scatter launch
+  std::vector<int> src, dst, pairs;
+  std::unordered_map<int64_t, HostModel *> by_id;
+  for (auto t : e->registry) by_id[e->models[t].id] = &e->models[t];
   for (auto &rq : req) {
-    HostModel *m = nullptr;
-    for (auto t : e->registry)
-      if (e->models[t].id == rq.first) m = &e->models[t];
-    if (!m) return fail(e, CALS_HIP_ERR_STATE, "internal: compress lost a model");
+    auto it = by_id.find(rq.first);
+    if (it == by_id.end()) return fail(e, CALS_HIP_ERR_STATE, "internal: compress lost a model");
+    HostModel *m = it->second;
     const int64_t off = rq.second, r = m->rank, col = m->col;
-    for (int n = 0; n < e->n_modes; n++) {
-      HIPCHK(move_columns_launch(e->factor[n], e->dtype, e->modes[n], col, r, off, e->stream));
-      HIPCHK(move_columns_launch(e->gram[n], CALS_F64, CALS_RMAX, col, r, off, e->stream));
-      if (e->ls_allocated) {
-        HIPCHK(move_columns_launch(e->prev[n], e->dtype, e->modes[n], col, r, off, e->stream));
-        HIPCHK(move_columns_launch(e->backup[n], e->dtype, e->modes[n], col, r, off, e->stream));
-      }
-      // the active sets of a model sit in its first column (64-bit words moved as such)
-      if (e->nnls_allocated)
-        HIPCHK(move_columns_launch(e->act[n], CALS_F64, e->modes[n], col, 1, off, e->stream));
-      if (e->nnls_ls_allocated)
-        HIPCHK(move_columns_launch(e->act_backup[n], CALS_F64, e->modes[n], col, 1, off, e->stream));
-    }
-    HIPCHK(move_columns_launch(e->lambda, CALS_F64, 1, col, r, off, e->stream));
-    if (e->ls_allocated) {
-      HIPCHK(move_columns_launch(e->prev_lambda, CALS_F64, 1, col, r, off, e->stream));
-      HIPCHK(move_columns_launch(e->backup_lambda, CALS_F64, 1, col, r, off, e->stream));
+    for (int64_t c = 0; c < r; c++) {
+      src.push_back((int)(col + c));
+      dst.push_back((int)(col + c - off));
     }
     for (int64_t i = col; i < col + r; i++) std::swap(e->occ[i - off], e->occ[i]);
     m->col -= off;
-    const int c32 = (int)m->col;
-    HIPCHK(hipMemcpyAsync(e->mt.col + m->slot, &c32, sizeof(int), hipMemcpyHostToDevice,
-                          e->stream));
-    HIPCHK(hipStreamSynchronize(e->stream));
+    pairs.push_back(m->slot);
+    pairs.push_back((int)m->col);
+  }
+  {
+    const size_t nc = src.size();
+    const int wpe = (e->dtype == CALS_F32) ? 1 : 2;
+    ColMoveArgs a{};
+    size_t words = 0;
+    auto add = [&](void *ptr, long long rows, int w) {
+      a.buf[a.n_bufs] = ColBuf{ptr, rows, w};
+      a.scratch_off[a.n_bufs] = (long long)words;
+      words += (size_t)rows * w * nc;
+      a.n_bufs++;
+    };
+    for (int n = 0; n < e->n_modes; n++) {
+      add(e->factor[n], e->modes[n], wpe);
+      add(e->gram[n], CALS_RMAX, 2);
+      if (e->ls_allocated) {
+        add(e->prev[n], e->modes[n], wpe);
+        add(e->backup[n], e->modes[n], wpe);
+      }
+      // the active sets of a model sit in its first column (64-bit words; the other columns are unused)
+      if (e->nnls_allocated) add(e->act[n], e->modes[n], 2);
+      if (e->nnls_ls_allocated) add(e->act_backup[n], e->modes[n], 2);
+    }
+    add(e->lambda, 1, 2);
+    if (e->ls_allocated) {
+      add(e->prev_lambda, 1, 2);
+      add(e->backup_lambda, 1, 2);
+    }
+    int rc = ensure_col_scratch(e, words, 2 * nc + pairs.size(), false);
+    if (rc) return rc;
+    std::vector<int> idx(src);
+    idx.insert(idx.end(), dst.begin(), dst.end());
+    idx.insert(idx.end(), pairs.begin(), pairs.end());
+    HIPCHK(hipMemcpyAsync(e->d_colidx, idx.data(), idx.size() * sizeof(int), hipMemcpyHostToDevice, e->stream));
+    a.src = e->d_colidx;
+    a.dst = e->d_colidx + nc;
+    a.n_cols = (int)nc;
+    a.scratch = e->col_scratch;
+    HIPCHK(gather_columns_launch(a, e->stream));
+    HIPCHK(scatter_columns_launch(a, e->stream));
+    HIPCHK(set_cols_launch(e->d_colidx + 2 * nc, (int)(pairs.size() / 2), e->mt.col, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));  // idx is a temporary
   }
   adjust_edges(e);
   return CALS_HIP_OK;
@@ -1284,6 +1360,9 @@ int cals_hip_destroy(cals_hip_engine *e) {
   }
   fr(e->rowdot);
   fr(e->d_nnls_status);
+  fr(e->col_scratch);
+  fr(e->d_colidx);
+  if (e->h_stage) (void)hipHostFree(e->h_stage);
   fr(e->partial);
   fr(e->tree.Tbuf);
   fr(e->tree.Pt);
@@ -1502,12 +1581,26 @@ int cals_hip_run(cals_hip_engine *e, cals_hip_report *rep) {
   HIPCHK(hipStreamSynchronize(e->stream));
   const double t_loop = now_ms();
   bool converged = e->queue.empty() && e->registry.empty();
+  // CALS_HIP_TIMING=1: host-clock split of the loop (device synchronised at every boundary)
+  static const bool timing = getenv("CALS_HIP_TIMING") != nullptr;
+  double tm[5] = {0, 0, 0, 0, 0}, tl = 0;
+  auto lap = [&](int k) {
+    if (!timing) return;
+    (void)hipStreamSynchronize(e->stream);
+    const double t = now_ms();
+    tm[k] += t - tl;
+    tl = t;
+  };
+  if (timing) tl = now_ms();
   while (!converged) {
     iter++;
     int rc = admit(e, nullptr);
     if (rc) return rc;
+    lap(0);
     if ((rc = sweep_once(e, true, true))) return rc;
+    lap(1);
     if ((rc = fetch_status(e))) return rc;
+    lap(2);
     if (e->prm.line_search)
       for (auto t : e->registry) {
         const int f = e->h_flags[e->models[t].slot];
@@ -1515,10 +1608,14 @@ int cals_hip_run(cals_hip_engine *e, cals_hip_report *rep) {
         if (f & 2) e->ls_failed++;
       }
     if ((rc = evict(e, nullptr))) return rc;
+    lap(3);
     converged = e->queue.empty() && e->registry.empty();
   }
   HIPCHK(hipStreamSynchronize(e->stream));
   const double t1 = now_ms();
+  if (timing)
+    fprintf(stderr, "cals_hip_run: %lld sweeps; admit %.1f ms, sweep %.1f ms, status %.1f ms, evict+compress %.1f ms\n",
+            (long long)iter, tm[0], tm[1], tm[2], tm[3]);
   if (rep) {
     rep->iter = iter;
     rep->n_ktensors = e->n_ktensors;

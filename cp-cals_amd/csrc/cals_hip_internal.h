@@ -243,5 +243,25 @@ hipError_t slice_sumsq_launch(const void *X, int src_dtype, long long I, long lo
 hipError_t move_columns_launch(void *buf, int dtype, long long rows, long long src_col,
                                long long ncols, long long off, hipStream_t st);
 
+// batched column gather / scatter over several buffers (eviction, compress)
+#define CALS_MAX_COLBUFS 56
+struct ColBuf {
+  void *ptr;
+  long long rows;
+  int words_per_elem;  // 4-byte words per element: 1 (float) or 2 (double, 64-bit masks)
+};
+struct ColMoveArgs {
+  ColBuf buf[CALS_MAX_COLBUFS];
+  int n_bufs;
+  const int *src, *dst;   // column indices, n_cols each (gather reads src, scatter writes dst)
+  int n_cols;
+  unsigned *scratch;      // compact copy: buffer b at scratch_off[b] (words), column k at rows * wpe * k
+  long long scratch_off[CALS_MAX_COLBUFS];
+  int zero_src_bufs;      // gather: zero the source columns of buffers [0, zero_src_bufs)
+};
+hipError_t gather_columns_launch(const ColMoveArgs &a, hipStream_t st);
+hipError_t scatter_columns_launch(const ColMoveArgs &a, hipStream_t st);
+hipError_t set_cols_launch(const int *pairs, int n, int *col, hipStream_t st);
+
 }  // namespace calship
 #endif

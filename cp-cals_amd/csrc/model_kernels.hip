@@ -1628,4 +1628,56 @@ hipError_t move_columns_launch(void *buf, int dtype, long long rows, long long s
   return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------
+// Batched column traffic of the MultiKtensor life cycle (eviction, compress): all buffers and all
+// columns of one operation in ONE launch.  A move goes through a compact scratch copy (gather the
+// source columns, then scatter them to their destinations): compress shifts models left into the
+// holes, so a destination may be another moved model's source.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) gather_columns_kernel(const ColMoveArgs a) {
+  const int k = blockIdx.x, b = blockIdx.y;
+  const ColBuf &cb = a.buf[b];
+  const long long words = cb.rows * cb.words_per_elem;
+  unsigned *src = static_cast<unsigned *>(cb.ptr) + words * a.src[k];
+  unsigned *dst = a.scratch + a.scratch_off[b] + words * k;
+  const bool zero = b < a.zero_src_bufs;
+  for (long long i = threadIdx.x; i < words; i += 256) {
+    dst[i] = src[i];
+    if (zero) src[i] = 0u;
+  }
+}
+
+__global__ void __launch_bounds__(256) scatter_columns_kernel(const ColMoveArgs a) {
+  const int k = blockIdx.x, b = blockIdx.y;
+  const ColBuf &cb = a.buf[b];
+  const long long words = cb.rows * cb.words_per_elem;
+  const unsigned *src = a.scratch + a.scratch_off[b] + words * k;
+  unsigned *dst = static_cast<unsigned *>(cb.ptr) + words * a.dst[k];
+  for (long long i = threadIdx.x; i < words; i += 256) dst[i] = src[i];
+}
+
+hipError_t gather_columns_launch(const ColMoveArgs &a, hipStream_t st) {
+  if (a.n_cols <= 0 || a.n_bufs <= 0) return hipSuccess;
+  hipLaunchKernelGGL(gather_columns_kernel, dim3(a.n_cols, a.n_bufs), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+
+hipError_t scatter_columns_launch(const ColMoveArgs &a, hipStream_t st) {
+  if (a.n_cols <= 0 || a.n_bufs <= 0) return hipSuccess;
+  hipLaunchKernelGGL(scatter_columns_kernel, dim3(a.n_cols, a.n_bufs), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+
+// mt.col[slot] = col for n (slot, col) pairs
+__global__ void set_cols_kernel(const int *pairs, int n, int *col) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n) col[pairs[2 * k]] = pairs[2 * k + 1];
+}
+
+hipError_t set_cols_launch(const int *pairs, int n, int *col, hipStream_t st) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(set_cols_kernel, dim3((n + 127) / 128), dim3(128), 0, st, pairs, n, col);
+  return hipGetLastError();
+}
+
 }  // namespace calship
