@@ -199,9 +199,6 @@ int dev_alloc_elems(cals_hip_engine *e, void **p, size_t n) {
   HIPCHK(hipMemsetAsync(*p, 0, std::max<size_t>(n, 1) * e->es, e->stream));
   return CALS_HIP_OK;
 }
-inline void *elem_ptr(const cals_hip_engine *e, void *base, long long idx) {
-  return (char *)base + (size_t)idx * e->es;
-}
 
 // MultiKtensor::adjust_edges, src/multi_ktensor.cpp:165-186 (cell 0 is never examined)
 int64_t active_cols_of(const int64_t *occ, int64_t n) {
@@ -999,47 +996,58 @@ int admit(cals_hip_engine *e, int64_t *n_admitted) {
   if (!admitted.empty()) {
     e->slots_dirty = true;
     tree_invalidate(e);
-    // Ktensor::attach: copy the models' factors into the buffer columns.  Models admitted back to
-    // back sit in adjacent columns, so each run goes up as ONE H2D per mode from a staging buffer.
-    size_t k0 = 0;
-    std::vector<double> stage;
-    std::vector<float> stage_f;
-    while (k0 < admitted.size()) {
-      size_t k1 = k0 + 1;
-      int64_t cols = e->models[admitted[k0]].rank;
-      while (k1 < admitted.size() &&
-             e->models[admitted[k1]].col == e->models[admitted[k0]].col + cols) {
-        cols += e->models[admitted[k1]].rank;
-        k1++;
-      }
-      const int64_t col0 = e->models[admitted[k0]].col;
-      for (int n = 0; n <= e->n_modes; n++) {  // n == n_modes: lambda
-        const int64_t rows = (n < e->n_modes) ? e->modes[n] : 1;
-        stage.resize((size_t)(rows * cols));
-        size_t off = 0;
-        for (size_t k = k0; k < k1; k++) {
-          const HostModel &m = e->models[admitted[k]];
-          const double *src = (n < e->n_modes) ? m.factors[n] : m.lambda;
-          std::memcpy(stage.data() + off, src, sizeof(double) * (size_t)(rows * m.rank));
-          off += (size_t)(rows * m.rank);
-        }
-        const bool f32 = (n < e->n_modes) && e->dtype == CALS_F32;
-        if (f32) {  // fp32 storage: the callers' fp64 factors are rounded once, on admission
-          stage_f.resize(stage.size());
-          for (size_t i = 0; i < stage.size(); i++) stage_f[i] = (float)stage[i];
-        }
-        void *dst = (n < e->n_modes) ? elem_ptr(e, e->factor[n], rows * col0) : (void *)(e->lambda + col0);
-        HIPCHK(hipMemcpyAsync(dst, f32 ? (const void *)stage_f.data() : (const void *)stage.data(),
-                              stage.size() * (f32 ? sizeof(float) : sizeof(double)),
-                              hipMemcpyHostToDevice, e->stream));
-        HIPCHK(hipStreamSynchronize(e->stream));  // stage is reused
-      }
-      k0 = k1;
+    // Ktensor::attach: copy the models' factors into the buffer columns -- all admitted models at
+    // once: packed (rounded to fp32 for an fp32 engine) into pinned host memory, ONE H2D, ONE scatter
+    // launch that writes every column of every factor and of lambda to its place.
+    std::vector<int> cols;
+    for (auto t : admitted) {
+      const HostModel &m = e->models[t];
+      for (int64_t c = 0; c < m.rank; c++) cols.push_back((int)(m.col + c));
     }
+    const size_t nc = cols.size();
+    const int wpe = (e->dtype == CALS_F32) ? 1 : 2;
+    ColMoveArgs ca{};
+    size_t words = 0;
+    for (int n = 0; n < e->n_modes; n++) {
+      ca.buf[n] = ColBuf{e->factor[n], (long long)e->modes[n], wpe};
+      ca.scratch_off[n] = (long long)words;
+      words += (size_t)e->modes[n] * wpe * nc;
+    }
+    ca.buf[e->n_modes] = ColBuf{e->lambda, 1, 2};
+    ca.scratch_off[e->n_modes] = (long long)words;
+    words += 2 * nc;
+    ca.n_bufs = e->n_modes + 1;
+    {
+      int rc = ensure_col_scratch(e, words, nc + desc.size() + new_slots.size(), true);
+      if (rc) return rc;
+    }
+    {
+      size_t k0 = 0;
+      for (auto t : admitted) {
+        const HostModel &m = e->models[t];
+        for (int n = 0; n < e->n_modes; n++) {
+          const size_t cnt = (size_t)(e->modes[n] * m.rank);
+          unsigned *dst = e->h_stage + ca.scratch_off[n] + (size_t)e->modes[n] * wpe * k0;
+          if (e->dtype == CALS_F32) {  // fp32 storage: the callers' fp64 factors are rounded once, on admission
+            float *f = reinterpret_cast<float *>(dst);
+            for (size_t i = 0; i < cnt; i++) f[i] = (float)m.factors[n][i];
+          } else {
+            std::memcpy(dst, m.factors[n], cnt * sizeof(double));
+          }
+        }
+        std::memcpy(e->h_stage + ca.scratch_off[e->n_modes] + 2 * k0, m.lambda, sizeof(double) * (size_t)m.rank);
+        k0 += (size_t)m.rank;
+      }
+    }
+    HIPCHK(hipMemcpyAsync(e->col_scratch, e->h_stage, words * sizeof(unsigned), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(e->d_colidx, cols.data(), nc * sizeof(int), hipMemcpyHostToDevice, e->stream));
+    ca.src = e->d_colidx;
+    ca.dst = e->d_colidx;
+    ca.n_cols = (int)nc;
+    ca.scratch = e->col_scratch;
+    HIPCHK(scatter_columns_launch(ca, e->stream));
     // per-slot scalars + Gramians of the new models, all modes (multi_ktensor.cpp:88-96)
-    int *d_desc = nullptr, *d_new = nullptr;
-    HIPCHK(hipMalloc((void **)&d_desc, desc.size() * sizeof(int)));
-    HIPCHK(hipMalloc((void **)&d_new, new_slots.size() * sizeof(int)));
+    int *d_desc = e->d_colidx + nc, *d_new = d_desc + desc.size();  // behind the column list
     HIPCHK(hipMemcpyAsync(d_desc, desc.data(), desc.size() * sizeof(int), hipMemcpyHostToDevice,
                           e->stream));
     HIPCHK(hipMemcpyAsync(d_new, new_slots.data(), new_slots.size() * sizeof(int),
@@ -1068,9 +1076,7 @@ int admit(cals_hip_engine *e, int64_t *n_admitted) {
     g.n_modes = e->n_modes;
     g.dtype = e->dtype;
     HIPCHK(gram_init_launch(g, e->stream));
-    HIPCHK(hipStreamSynchronize(e->stream));
-    HIPCHK(hipFree(d_desc));
-    HIPCHK(hipFree(d_new));
+    HIPCHK(hipStreamSynchronize(e->stream));  // cols / desc / new_slots are temporaries
   }
   if (n_admitted) *n_admitted = count;
   return CALS_HIP_OK;
