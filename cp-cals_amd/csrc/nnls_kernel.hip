@@ -75,6 +75,8 @@ __device__ __forceinline__ unsigned long long uniform64(unsigned long long v) {
 }
 
 struct WaveScratch {
+  unsigned long long cached;  // passive set whose factor is in Lw / dg (0: none)
+  double dg;                  // lane p: L[p][p] of that factor
   double *Lw;   // strict lower triangle of the Cholesky factor of G[P,P], row p at Lw + p * ldw
   int ldw;
   int *idx;     // idx[p]: component of the p-th passive entry
@@ -84,7 +86,10 @@ struct WaveScratch {
 
 // calculate_sp (update.cpp:18-48): x[i] = (G[P,P]^-1 y[P])[i] for i in P, 0 elsewhere.
 // pas: passive set (wave-uniform), np = popcount(pas) >= 1.  false: the Cholesky failed (CholFail).
-__device__ bool solve_passive(const double *Hs, int r, const WaveScratch &ws, unsigned long long pas,
+// The factor of the last passive set stays in the wave's tile: consecutive rows of a wave (and the
+// first solve of a row after the previous row's last) very often share it -- all-passive rows of a
+// model with positive factors all do -- and then only the two substitutions run.
+__device__ bool solve_passive(const double *Hs, int r, WaveScratch &ws, unsigned long long pas,
                               int np, double y, int lane, double &x) {
   const bool mine = (pas >> lane) & 1ull;
   if (mine) {
@@ -100,6 +105,17 @@ __device__ bool solve_passive(const double *Hs, int r, const WaveScratch &ws, un
   double dg = 1.0;
   double *Lw = ws.Lw;
   const int ldw = ws.ldw;
+  if (pas == ws.cached) {
+    dg = ws.dg;
+    for (int j = 0; j < np; ++j) {  // L z = b with the cached factor, same operation order
+      const double zj = bcast(t, j) / bcast(dg, j);
+      if (p == j)
+        t = zj;
+      else if (valid && p > j)
+        t -= Lw[p * ldw + j] * zj;
+    }
+  } else {
+  ws.cached = 0;
   for (int j = 0; j < np; ++j) {
     const int ij = __builtin_amdgcn_readfirstlane(ws.idx[j]);
     const bool below = valid && p > j;
@@ -139,6 +155,9 @@ __device__ bool solve_passive(const double *Hs, int r, const WaveScratch &ws, un
     }
     WAVE_SYNC();
   }
+  ws.cached = pas;
+  ws.dg = dg;
+  }
   for (int j = np - 1; j >= 0; --j) {  // L^T x = z
     const double xj = bcast(t, j) / bcast(dg, j);
     if (p == j)
@@ -176,6 +195,8 @@ __global__ void __launch_bounds__(256) nnls_kernel(const NnlsArgs a) {
 
   double *Hs = reinterpret_cast<double *>(nnls_dyn);  // r x r, ld = r
   WaveScratch ws;
+  ws.cached = 0;
+  ws.dg = 1.0;
   {
     const int ldw = r | 1;
     const size_t per_wave = (size_t)a.rmax * (a.rmax | 1) + 64 + 64 + 32;  // doubles (idx: 64 ints)
