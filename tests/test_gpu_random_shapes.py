@@ -35,7 +35,13 @@ def _cases(n, seed):
     return out
 
 
-@pytest.mark.parametrize("modes,ranks,plan,dtype,seed", _cases(80, 20260101))
+# soak runs: CALS_SOAK_SHAPES / CALS_SOAK_LIFE set the number of cases, CALS_SOAK_SEED another stream
+_N_SHAPES = int(os.environ.get("CALS_SOAK_SHAPES", "80"))
+_N_LIFE = int(os.environ.get("CALS_SOAK_LIFE", "24"))
+_SEED = int(os.environ.get("CALS_SOAK_SEED", "0"))
+
+
+@pytest.mark.parametrize("modes,ranks,plan,dtype,seed", _cases(_N_SHAPES, 20260101 + _SEED))
 def test_random_shape_mttkrp_and_sweeps(cc, oracle, inputs, modes, ranks, plan, dtype, seed):
     old = os.environ.get("CALS_HIP_TREE")
     os.environ["CALS_HIP_TREE"] = plan
@@ -89,7 +95,7 @@ def _life_cases(n, seed):
     return out
 
 
-@pytest.mark.parametrize("modes,ranks,buffer,plan,ls,tol,seed", _life_cases(24, 777))
+@pytest.mark.parametrize("modes,ranks,buffer,plan,ls,tol,seed", _life_cases(_N_LIFE, 777 + _SEED))
 def test_random_queue_life_cycle(cc, oracle, inputs, modes, ranks, buffer, plan, ls, tol, seed):
     """Queue longer than the buffer, tolerance-driven eviction, compress, optional line search: the
     same admission order, per-model iteration counts and fitted tensors as the oracle, under every
@@ -99,7 +105,9 @@ def test_random_queue_life_cycle(cc, oracle, inputs, modes, ranks, buffer, plan,
     os.environ["CALS_HIP_TREE"] = plan
     try:
         X = inputs.low_rank_tensor(modes, 5, seed=seed % 1000)[0] + 0.05 * inputs.tensor(modes, seed % 977)
-        base = make_models(inputs, modes, ranks, seed=1 + seed % 991)
+        # every third case: jackknife replicas (mode 0, fiber = model index mod I_0) among the models
+        jk = [((0, k % modes[0]) if (k + seed) % 2 == 0 else None) for k in range(len(ranks))] if seed % 3 == 0 else None
+        base = make_models(inputs, modes, ranks, seed=1 + seed % 991, jk=jk)
         kw = dict(max_iterations=30, tol=tol, line_search=ls, line_search_interval=3,
                   line_search_method=(seed >> 3) & 1)  # NO_ERROR_CHECKING or ERROR_CHECKING_SERIAL
         if not ls and (seed >> 4) & 1:
@@ -110,12 +118,12 @@ def test_random_queue_life_cycle(cc, oracle, inputs, modes, ranks, buffer, plan,
         e = cc.Engine(modes, buffer)
         e.set_tensor(X)
         e.set_params(cc.default_params(**kw))
-        gm = [cc.Model([f.copy() for f in fs], lam.copy()) for fs, lam, _ in base]
+        gm = [cc.Model([f.copy() for f in fs], lam.copy(), jk=j) for fs, lam, j in base]
         for m in gm:
             e.enqueue(m)
         rep = e.run()
         e.close()
-        om = [oracle.Model(fs, lam) for fs, lam, _ in base]
+        om = [oracle.Model(fs, lam, jk=j) for fs, lam, j in base]
         ro = oracle.cp_cals(X, modes, om, oracle.default_params(mttkrp_method=oracle.MTTKRP, buffer_size=buffer, **kw))
         assert (rep.iter, rep.n_ktensors, rep.ktensor_comp_sum) == (ro.iter, ro.n_ktensors, ro.ktensor_comp_sum)
         assert (rep.ls_performed, rep.ls_failed) == (ro.ls_performed, ro.ls_failed)
