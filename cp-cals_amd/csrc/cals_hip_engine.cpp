@@ -1279,7 +1279,8 @@ int cals_hip_create_ex(cals_hip_engine **out, int n_modes, const int64_t *modes,
       pc.m_blocks = (tiles + max_mt - 1) / max_mt;
       pc.MT = (tiles + pc.m_blocks - 1) / pc.m_blocks;
       pc.k_big = tiles - pc.m_blocks * (pc.MT - 1);
-      t_elems = std::max(t_elems, (size_t)buffer_size * (size_t)L.S * (size_t)L.Mp);
+      // whole column blocks: the TTM stores the zero columns that pad the last block as well
+      t_elems = std::max(t_elems, nb_max * CALS_BN * (size_t)L.S * (size_t)L.Mp);
       pt_elems = std::max(pt_elems, nb_max * (size_t)L.Ap * CALS_BN);
     }
     if ((rc = dev_alloc_elems(e, &tp.Pt, pt_elems))) return rc;

@@ -228,14 +228,15 @@ static __device__ __forceinline__ void run(const TtmArgs &a, const int m0, const
   T *const Tout = static_cast<T *>(a.Tout);
   const bool st = !DIAG(a.dbg & 1);  // CALS_DIAG, dbg 1 (timing only): no T stores
 
+  // Columns R .. NB * 128 - 1 of the last column block are stored too (zeros: P is zero padded there;
+  // the engine sizes T for whole column blocks): a per-lane column predicate costs every one of the
+  // 4 MT stores of a flush a saveexec / branch / restore.
   // fp64: per register r the column krow + 4r of this wave
   T *tc[4];
-  bool cv[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int gc = nb * CALS_BN + wave * 16 + krow + 4 * r;
-    cv[r] = gc < a.R && st;
-    tc[r] = Tout + ((long long)(gc < a.R ? gc : 0) * S) * a.Mp + m0 + lcol;
+    tc[r] = Tout + ((long long)gc * S) * a.Mp + m0 + lcol;
   }
   // fp32: T flush through a per-wave LDS staging tile (two tiles = 32 rows = one 128-byte line per
   // column), so that every global_store_dwordx4 writes 8 whole lines
@@ -247,13 +248,13 @@ static __device__ __forceinline__ void run(const TtmArgs &a, const int m0, const
   for (int h = 0; h < 2; ++h) {
     const int c8 = (lane >> 3) + 8 * h;
     const int gc = nb * CALS_BN + wave * 16 + c8;
-    tv[h] = gc < a.R && st;
-    tb[h] = Tout + ((long long)(gc < a.R ? gc : 0) * S) * a.Mp + m0 + 4 * j8;
+    tv[h] = st;
+    tb[h] = Tout + ((long long)gc * S) * a.Mp + m0 + 4 * j8;
   }
   // fp32, odd MT: the last tile alone (16 rows = 64 B per column, 4 lanes per column)
   const int gc4 = nb * CALS_BN + wave * 16 + (lane >> 2);
-  const bool tv4 = gc4 < a.R && st;
-  T *const tb4 = Tout + ((long long)(gc4 < a.R ? gc4 : 0) * S) * a.Mp + m0 + 4 * (lane & 3);
+  const bool tv4 = st;
+  T *const tb4 = Tout + ((long long)gc4 * S) * a.Mp + m0 + 4 * (lane & 3);
 
   // end of an s: G += T * Q[s, c]; T -> HBM (non-temporal: written once, read once by the
   // contraction); T = 0
@@ -266,7 +267,7 @@ static __device__ __forceinline__ void run(const TtmArgs &a, const int m0, const
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           gacc[t][r] += tacc[t][r] * qv[r];
-          if (cv[r]) __builtin_nontemporal_store(tacc[t][r], tc[r] + so + 16 * t);
+          if (st) __builtin_nontemporal_store(tacc[t][r], tc[r] + so + 16 * t);
         }
         tacc[t] = (acc_t){0, 0, 0, 0};
       }
