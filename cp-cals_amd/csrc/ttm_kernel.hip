@@ -117,9 +117,11 @@ static __device__ __forceinline__ void run(const TtmArgs &a, const int m0, const
 
   const long long S = a.S;
   const int nAb = a.Ap >> 4;
-  const long long s_begin = S * tm / a.T;
-  const long long s_end = S * (tm + 1) / a.T;
-  const long long n_units = (s_end - s_begin) * nAb;
+  // 32-bit loop state (S is one mode's size): a 64-bit trip count made the compiler carry the stage
+  // counter through VALU compares (v_cmp_le_i64, v_cndmask + v_readfirstlane) in every stage
+  const int s_begin = (int)(S * tm / a.T);
+  const int s_end = (int)(S * (tm + 1) / a.T);
+  const int n_units = (s_end - s_begin) * nAb;
 
 
   acc_t tacc[MT], gacc[MT];
@@ -189,7 +191,7 @@ static __device__ __forceinline__ void run(const TtmArgs &a, const int m0, const
           ...);
     }(std::make_integer_sequence<int, C::NDMA>{});
   };
-  auto issue_all = [&](int ab, long long s, int bufi) {
+  auto issue_all = [&](int ab, int s, int bufi) {
     const T *src_slab = Xp + (long long)a.Mp * (16 * ab) + slab_stride_s * s;
     const T *p_slab = Pt_nb + (long long)(16 * ab) * CALS_BN;
     const T *q_row = Qm + s;
@@ -200,16 +202,16 @@ static __device__ __forceinline__ void run(const TtmArgs &a, const int m0, const
   };
 
   int ab_c = 0;
-  long long s_c = s_begin;
+  int s_c = s_begin;
   if (n_units > 0) issue_all(ab_c, s_c, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   int ab_1 = ab_c + 1;
-  long long s_1 = s_c;
+  int s_1 = s_c;
   if (ab_1 >= nAb) { ab_1 = 0; s_1++; }
   if (n_units > 1) issue_all(ab_1, s_1, 1);
   int ab_2 = ab_1 + 1;
-  long long s_2 = s_1;
+  int s_2 = s_1;
   if (ab_2 >= nAb) { ab_2 = 0; s_2++; }
 
   const unsigned lane_off = (unsigned)((krow * C::LDL + lcol) * C::ES);
@@ -258,9 +260,9 @@ static __device__ __forceinline__ void run(const TtmArgs &a, const int m0, const
 
   // end of an s: G += T * Q[s, c]; T -> HBM (non-temporal: written once, read once by the
   // contraction); T = 0
-  auto flush = [&](long long s, const T (&qv)[C::NQ]) {
+  auto flush = [&](int s, const T (&qv)[C::NQ]) {
     asm volatile("" ::: "memory");
-    const long long so = s * a.Mp;
+    const long long so = (long long)s * a.Mp;
     if constexpr (C::ES == 8) {
 #pragma unroll
       for (int t = 0; t < MT; ++t) {
@@ -313,7 +315,7 @@ static __device__ __forceinline__ void run(const TtmArgs &a, const int m0, const
   auto unit_loop = [&]<bool LATE>() {
     unsigned long long dg_vm = 0, dg_bar = 0, dg_per = 0, dg_n = 0, dg_last = 0;  // CALS_DIAG sums
     bool pend = false;       // LATE: flush of the previous unit deferred behind this unit's barrier
-    long long s_pend = 0;
+    int s_pend = 0;
     T q_pend[C::NQ] = {};
     // DMA sources of the unit two stages ahead and the LDS addresses of the next stage are carried
     // across iterations and advanced INSIDE the MFMA stream (right behind the last DMA issue), by
