@@ -161,7 +161,7 @@ __global__ void __launch_bounds__(512, 2) mttkrp3_kernel(const MttkrpArgs a) {
                                        (LDS_AS void *)(dst + C::SLAB + wave * C::QPE), 4, 0, 0);
     }
   };
-  auto issue_all = [&](long long ab, long long s, int bufi) {
+  auto issue_all = [&](int ab, int s, int bufi) {
     const T *src_slab = Xp + (long long)a.Mp * (16 * ab) + slab_stride_s * s;
     const T *q_row = Qm + s;
     T *dst = lds + bufi * C::BUF;
@@ -170,21 +170,24 @@ __global__ void __launch_bounds__(512, 2) mttkrp3_kernel(const MttkrpArgs a) {
     }(std::make_integer_sequence<int, C::NP + 1>{});
   };
 
-  const long long n_units = u_end - u_begin;
-  long long ab_c = 0, s_c = 0;
+  // 32-bit loop state (the launcher refuses S or a workgroup's unit count >= 2^31): 64-bit counters
+  // went through VALU compares in every stage
+  const int Si = (int)S;
+  const int n_units = (int)(u_end - u_begin);
+  int ab_c = 0, s_c = 0;
   if (n_units > 0) {
-    ab_c = u_begin / S;
-    s_c = u_begin - ab_c * S;
+    ab_c = (int)(u_begin / S);
+    s_c = (int)(u_begin - ab_c * S);
     issue_all(ab_c, s_c, 0);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   // (ab, s) of unit u+1 and u+2, kept incrementally (no 64-bit division in the loop)
-  long long ab_1 = ab_c, s_1 = s_c + 1;
-  if (s_1 >= S) { s_1 = 0; ab_1++; }
+  int ab_1 = ab_c, s_1 = s_c + 1;
+  if (s_1 >= Si) { s_1 = 0; ab_1++; }
   if (n_units > 1) issue_all(ab_1, s_1, 1);
-  long long ab_2 = ab_1, s_2 = s_1 + 1;
-  if (s_2 >= S) { s_2 = 0; ab_2++; }
+  int ab_2 = ab_1, s_2 = s_1 + 1;
+  if (s_2 >= Si) { s_2 = 0; ab_2++; }
 
   const unsigned lane_off = (unsigned)((krow * C::LDL + lcol) * C::ES);
   const unsigned lds0 = (unsigned)(size_t)((LDS_AS const char *)lds_raw);
@@ -192,11 +195,11 @@ __global__ void __launch_bounds__(512, 2) mttkrp3_kernel(const MttkrpArgs a) {
 
   T preg[4] = {0, 0, 0, 0};
   int buf = 0;
-  auto load_p = [&](long long ab) {
+  auto load_p = [&](int ab) {
     // P[16ab + 4q + krow, col]: inline-asm load with its own wait (once per S units)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const int arow = (int)(16 * ab) + 4 * q + krow;
+      const int arow = 16 * ab + 4 * q + krow;
       const bool ok = (arow < a.A) && cvalid;
       const T *ptr = Pm + (ok ? arow + a.ldP * col : 0);
       T v;
@@ -209,13 +212,13 @@ __global__ void __launch_bounds__(512, 2) mttkrp3_kernel(const MttkrpArgs a) {
   };
 
   auto unit_loop = [&]<bool LATE>() {
-    long long ab_loaded = -1;
-    for (long long iu = 0; iu < n_units; ++iu) {
+    int ab_loaded = -1;
+    for (int iu = 0; iu < n_units; ++iu) {
       const int buf_n = (buf == 2) ? 0 : buf + 1;
       const int buf_nn = (buf_n == 2) ? 0 : buf_n + 1;
       const unsigned base = lds0 + (unsigned)(buf * C::BUF * C::ES) + lane_off;
       const bool fetch = (iu + 2 < n_units) && !DIAG(a.dbg_no_dma);
-      const T *src_slab = Xp + (long long)a.Mp * (16 * ab_2) + slab_stride_s * s_2;
+      const T *src_slab = Xp + (long long)a.Mp * (16 * ab_2) + slab_stride_s * (long long)s_2;
       const T *q_row = Qm + s_2;
       T *dst = lds + buf_nn * C::BUF;
 
@@ -278,7 +281,7 @@ __global__ void __launch_bounds__(512, 2) mttkrp3_kernel(const MttkrpArgs a) {
       ab_1 = ab_2;
       s_1 = s_2;
       s_2 = s_2 + 1;
-      if (s_2 >= S) { s_2 = 0; ab_2++; }
+      if (s_2 >= Si) { s_2 = 0; ab_2++; }
     }
   };
   // DMA pieces ride on the MFMA steps of one half of a slab: the half must have NP + 1 of them
@@ -325,6 +328,9 @@ static hipError_t launch3_mt(int m_blocks, const MttkrpArgs &a, hipStream_t st) 
 }
 
 hipError_t mttkrp3_launch(int MT, int m_blocks, const MttkrpArgs &a, hipStream_t st) {
+  // the kernel keeps its stage counters in 32 bits
+  if (a.S >= (1ll << 31) || ((long long)(a.Ap >> 4) * a.S) / (a.T > 0 ? a.T : 1) >= (1ll << 31) - 2)
+    return hipErrorInvalidValue;
   if (a.dtype == CALS_F32) {
     switch (MT) {
 #define CASE(N) case N: return launch3_mt<N, float>(m_blocks, a, st);

@@ -544,6 +544,7 @@ int ttm_max_mt(int dtype) { return dtype == CALS_F32 ? 20 : 10; }
 
 hipError_t ttm_launch(const TtmArgs &a, hipStream_t st) {
   if (a.MT < 1 || a.MT > ttm_max_mt(a.dtype)) return hipErrorInvalidValue;
+  if (a.S >= (1ll << 31) / (a.Ap >> 4 ? a.Ap >> 4 : 1)) return hipErrorInvalidValue;  // 32-bit stage counters
   if (a.dtype == CALS_F32) {
     switch (a.MT) {
 #define CASE(N) case N: return ttm_launch_mt<N, float>(a, st);
