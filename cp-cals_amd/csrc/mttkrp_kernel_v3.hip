@@ -180,6 +180,7 @@ __global__ void __launch_bounds__(512, 2) mttkrp3_kernel(const MttkrpArgs a) {
     s_c = (int)(u_begin - ab_c * S);
     issue_all(ab_c, s_c, 0);
   }
+  const int ab_first = ab_c, s_first = s_c;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   // (ab, s) of unit u+1 and u+2, kept incrementally (no 64-bit division in the loop)
@@ -217,9 +218,17 @@ __global__ void __launch_bounds__(512, 2) mttkrp3_kernel(const MttkrpArgs a) {
       const int buf_n = (buf == 2) ? 0 : buf + 1;
       const int buf_nn = (buf_n == 2) ? 0 : buf_n + 1;
       const unsigned base = lds0 + (unsigned)(buf * C::BUF * C::ES) + lane_off;
-      const bool fetch = (iu + 2 < n_units) && !DIAG(a.dbg_no_dma);
-      const T *src_slab = Xp + (long long)a.Mp * (16 * ab_2) + slab_stride_s * (long long)s_2;
-      const T *q_row = Qm + s_2;
+      // fp64: the DMA of unit iu + 2 is issued unconditionally -- in the last two stages it re-reads the
+      // range's first slab into the buffer nobody consumes any more (waited for after the loop) --
+      // instead of a uniform branch in front of every DMA instruction (ttm_kernel.hip has the numbers;
+      // the fp32 kernels measured slower with it)
+      constexpr bool ALWAYS = (C::ES == 8);
+      const bool in_range = iu + 2 < n_units;
+      const bool fetch = (ALWAYS || in_range) && !DIAG(a.dbg_no_dma);
+      const int ab_f = (in_range || !ALWAYS) ? ab_2 : ab_first;
+      const int s_f = (in_range || !ALWAYS) ? s_2 : s_first;
+      const T *src_slab = Xp + (long long)a.Mp * (16 * ab_f) + slab_stride_s * (long long)s_f;
+      const T *q_row = Qm + s_f;
       T *dst = lds + buf_nn * C::BUF;
 
       if constexpr (LATE) {
