@@ -1347,6 +1347,7 @@ int cals_hip_create_ex(cals_hip_engine **out, int n_modes, const int64_t *modes,
 
 int cals_hip_destroy(cals_hip_engine *e) {
   if (!e) return CALS_HIP_OK;
+  HIPCHK(hipSetDevice(e->device));  // a process may hold engines on several GPUs
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   auto fr = [](void *p) {
     if (p) (void)hipFree(p);
@@ -1411,6 +1412,7 @@ namespace {
 int set_tensor_impl(cals_hip_engine *e, const void *X_host, int src_dtype) {
   if (!e || !X_host) return CALS_HIP_ERR_ARG;
   if (!e->stream) return fail(e, CALS_HIP_ERR_STATE, "engine not initialised");
+  HIPCHK(hipSetDevice(e->device));
   long long total = 1;
   for (int n = 0; n < e->n_modes; n++) total *= e->modes[n];
   const size_t src_es = (src_dtype == CALS_F32) ? sizeof(float) : sizeof(double);
@@ -1521,12 +1523,14 @@ int cals_hip_enqueue(cals_hip_engine *e, int64_t rank, double *const *factors, d
 
 int cals_hip_admit(cals_hip_engine *e, int64_t *n_admitted) {
   if (!e) return CALS_HIP_ERR_ARG;
+  HIPCHK(hipSetDevice(e->device));  // a process may hold engines on several GPUs
   if (!e->has_tensor) return fail(e, CALS_HIP_ERR_STATE, "set_tensor first");
   return admit(e, n_admitted);
 }
 
 int cals_hip_sweep(cals_hip_engine *e, int64_t n_sweeps) {
   if (!e) return CALS_HIP_ERR_ARG;
+  HIPCHK(hipSetDevice(e->device));  // a process may hold engines on several GPUs
   if (!e->has_tensor) return fail(e, CALS_HIP_ERR_STATE, "set_tensor first");
   for (int64_t s = 0; s < n_sweeps; s++) {
     int rc = sweep_once(e, false);
@@ -1537,6 +1541,7 @@ int cals_hip_sweep(cals_hip_engine *e, int64_t n_sweeps) {
 
 int cals_hip_evict(cals_hip_engine *e, int64_t *n_evicted) {
   if (!e) return CALS_HIP_ERR_ARG;
+  HIPCHK(hipSetDevice(e->device));  // a process may hold engines on several GPUs
   int rc = fetch_status(e);
   if (rc) return rc;
   return evict(e, n_evicted);
@@ -1547,6 +1552,7 @@ int cals_hip_evict(cals_hip_engine *e, int64_t *n_evicted) {
 // engine runs (cp-cals_amd/multi_gpu.py: work-queue hand-off between GPUs).
 int cals_hip_step(cals_hip_engine *e, int64_t *n_admitted, int64_t *n_evicted) {
   if (!e) return CALS_HIP_ERR_ARG;
+  HIPCHK(hipSetDevice(e->device));  // a process may hold engines on several GPUs
   if (!e->has_tensor) return fail(e, CALS_HIP_ERR_STATE, "set_tensor first");
   if (n_admitted) *n_admitted = 0;
   if (n_evicted) *n_evicted = 0;
@@ -1581,6 +1587,7 @@ int cals_hip_get_report(const cals_hip_engine *e, cals_hip_report *rep) {
 
 int cals_hip_run(cals_hip_engine *e, cals_hip_report *rep) {
   if (!e) return CALS_HIP_ERR_ARG;
+  HIPCHK(hipSetDevice(e->device));  // a process may hold engines on several GPUs
   if (!e->has_tensor) return fail(e, CALS_HIP_ERR_STATE, "set_tensor first");
   const double t0 = now_ms();
   e->n_ktensors = e->comp_sum = e->ls_performed = e->ls_failed = 0;
@@ -1649,6 +1656,7 @@ int64_t cals_hip_queue_size(const cals_hip_engine *e) { return e ? (int64_t)e->q
 
 int cals_hip_synchronize(cals_hip_engine *e) {
   if (!e) return CALS_HIP_ERR_ARG;
+  HIPCHK(hipSetDevice(e->device));  // a process may hold engines on several GPUs
   HIPCHK(hipStreamSynchronize(e->stream));
   return CALS_HIP_OK;
 }
@@ -1666,6 +1674,7 @@ int cals_hip_debug_mttkrp(cals_hip_engine *e, int mode, double *G_host) {
 
 int cals_hip_debug_mttkrp_path(cals_hip_engine *e, int mode, int path, double *G_host) {
   if (!e || !G_host || mode < 0 || mode >= e->n_modes) return CALS_HIP_ERR_ARG;
+  HIPCHK(hipSetDevice(e->device));  // a process may hold engines on several GPUs
   if (!e->has_tensor) return fail(e, CALS_HIP_ERR_STATE, "set_tensor first");
   if (e->registry.empty()) return fail(e, CALS_HIP_ERR_STATE, "no model in flight");
   if (path != CALS_HIP_PATH_PLAIN && path != CALS_HIP_PATH_FIRST && path != CALS_HIP_PATH_SECOND)
@@ -1729,6 +1738,7 @@ int cals_hip_debug_mttkrp_path(cals_hip_engine *e, int mode, int path, double *G
 
 int cals_hip_debug_get_factor(cals_hip_engine *e, int mode, double *host) {
   if (!e || !host || mode < 0 || mode >= e->n_modes) return CALS_HIP_ERR_ARG;
+  HIPCHK(hipSetDevice(e->device));  // a process may hold engines on several GPUs
   const size_t n = (size_t)(e->modes[mode] * e->end);
   if (e->dtype == CALS_F32) {
     std::vector<float> hf(n);
@@ -1746,6 +1756,7 @@ int cals_hip_debug_get_factor(cals_hip_engine *e, int mode, double *host) {
 
 int cals_hip_debug_get_lambda(cals_hip_engine *e, double *host) {
   if (!e || !host) return CALS_HIP_ERR_ARG;
+  HIPCHK(hipSetDevice(e->device));  // a process may hold engines on several GPUs
   HIPCHK(hipMemcpyAsync(host, e->lambda, sizeof(double) * (size_t)e->end, hipMemcpyDeviceToHost,
                         e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
@@ -1754,6 +1765,7 @@ int cals_hip_debug_get_lambda(cals_hip_engine *e, double *host) {
 
 int cals_hip_debug_get_gramian(cals_hip_engine *e, int mode, double *host) {
   if (!e || !host || mode < 0 || mode >= e->n_modes) return CALS_HIP_ERR_ARG;
+  HIPCHK(hipSetDevice(e->device));  // a process may hold engines on several GPUs
   HIPCHK(hipMemcpyAsync(host, e->gram[mode], sizeof(double) * (size_t)(CALS_RMAX * e->end),
                         hipMemcpyDeviceToHost, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
@@ -1763,6 +1775,7 @@ int cals_hip_debug_get_gramian(cals_hip_engine *e, int mode, double *host) {
 int cals_hip_debug_model_status(cals_hip_engine *e, int64_t ticket, cals_hip_model_status *st,
                                 int64_t *col) {
   if (!e || !st || ticket < 0 || ticket >= (int64_t)e->models.size()) return CALS_HIP_ERR_ARG;
+  HIPCHK(hipSetDevice(e->device));  // a process may hold engines on several GPUs
   const HostModel &m = e->models[(size_t)ticket];
   if (m.state != 1) {
     *st = m.st;
@@ -1782,6 +1795,7 @@ int cals_hip_debug_model_status(cals_hip_engine *e, int64_t ticket, cals_hip_mod
 
 int cals_hip_debug_get_norms(cals_hip_engine *e, double *X_norm, double *jk_norms) {
   if (!e) return CALS_HIP_ERR_ARG;
+  HIPCHK(hipSetDevice(e->device));  // a process may hold engines on several GPUs
   if (!e->has_tensor) return fail(e, CALS_HIP_ERR_STATE, "set_tensor first");
   if (X_norm) *X_norm = e->X_norm;
   if (jk_norms) std::memcpy(jk_norms, e->jk_norms.data(), e->jk_norms.size() * sizeof(double));
@@ -1790,6 +1804,7 @@ int cals_hip_debug_get_norms(cals_hip_engine *e, double *X_norm, double *jk_norm
 
 int cals_hip_set_profiling(cals_hip_engine *e, int enabled) {
   if (!e) return CALS_HIP_ERR_ARG;
+  HIPCHK(hipSetDevice(e->device));  // a process may hold engines on several GPUs
   if (!enabled) prof_collect(e);
   e->profiling = enabled < 0 ? 0 : (enabled > 2 ? 2 : enabled);
   return CALS_HIP_OK;
@@ -1797,6 +1812,7 @@ int cals_hip_set_profiling(cals_hip_engine *e, int enabled) {
 
 int cals_hip_get_kernel_stats(cals_hip_engine *e, cals_hip_kernel_stats *out) {
   if (!e || !out) return CALS_HIP_ERR_ARG;
+  HIPCHK(hipSetDevice(e->device));  // a process may hold engines on several GPUs
   prof_collect(e);
   *out = e->stats;
   return CALS_HIP_OK;
@@ -1804,6 +1820,7 @@ int cals_hip_get_kernel_stats(cals_hip_engine *e, cals_hip_kernel_stats *out) {
 
 int cals_hip_reset_kernel_stats(cals_hip_engine *e) {
   if (!e) return CALS_HIP_ERR_ARG;
+  HIPCHK(hipSetDevice(e->device));
   prof_collect(e);
   e->stats = cals_hip_kernel_stats{};
   return CALS_HIP_OK;
@@ -1813,6 +1830,7 @@ void *cals_hip_stream(cals_hip_engine *e) { return e ? (void *)e->stream : nullp
 
 int cals_hip_debug_ttm_trace(cals_hip_engine *e, uint64_t *out, int n) {
   if (!e || !out || n < 1 || n > 16 * 2048) return CALS_HIP_ERR_ARG;
+  HIPCHK(hipSetDevice(e->device));  // a process may hold engines on several GPUs
   if (!e->dbg_trace) return fail(e, CALS_HIP_ERR_STATE, "create the engine with CALS_TTM_TRACE=1");
   HIPCHK(hipStreamSynchronize(e->stream));
   HIPCHK(hipMemcpy(out, e->dbg_trace, (size_t)n * sizeof(uint64_t), hipMemcpyDeviceToHost));
@@ -1821,6 +1839,7 @@ int cals_hip_debug_ttm_trace(cals_hip_engine *e, uint64_t *out, int n) {
 
 int cals_hip_debug_clock(cals_hip_engine *e, int n_workgroups, double *cycles_median, double *ghz_median) {
   if (!e || !e->dbg_clock || n_workgroups < 1 || n_workgroups > 4096) return CALS_HIP_ERR_ARG;
+  HIPCHK(hipSetDevice(e->device));  // a process may hold engines on several GPUs
   std::vector<unsigned long long> h((size_t)2 * n_workgroups);
   HIPCHK(hipMemcpy(h.data(), e->dbg_clock, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   std::vector<double> cyc, ghz;

@@ -5,12 +5,26 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #define CALS_MAX_MODES 8
 #define CALS_RMAX 64          // rank limit per model; leading dimension of the Gramian stores
 #define CALS_RFAST 32         // ranks up to this run the register-resident update bodies
 #define CALS_BN 128           // columns of the multi-factor per MTTKRP workgroup
 
 namespace calship {
+
+// hipFuncSetAttribute applies to the current device only: one flag per device for every kernel
+// instantiation that raises its dynamic LDS limit (a process may drive several GPUs, one engine each).
+struct AttrOnce {
+  std::atomic<unsigned long long> done{0};
+  bool need() {
+    int d = 0;
+    (void)hipGetDevice(&d);
+    const unsigned long long bit = 1ull << (d & 63);
+    return (done.fetch_or(bit) & bit) == 0;
+  }
+};
 
 // ---------------------------------------------------------------------------------------------
 // MTTKRP  G[m,c] = sum_{a,s} Xp[m,a,s] * P[a,c] * Q[s,c]     (DESIGN.md "MTTKRP kernel")

@@ -1083,21 +1083,19 @@ hipError_t update_launch(const UpdateArgs &a_in, int rmax_needed, hipStream_t st
     dyn = 0;
   }
   if (big > dyn) dyn = big;  // the two uses of the dynamic region never coexist in one workgroup
-  static size_t attr_f64 = 0, attr_f32 = 0;
+  static AttrOnce once_f64, once_f32;  // the limit is raised to the whole budget, once per device
   if (a.dtype == CALS_F32) {
-    if (dyn > attr_f32) {
+    if (once_f32.need()) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&update_kernel<float>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)budget);
       if (e != hipSuccess) return e;
-      attr_f32 = budget;
     }
     hipLaunchKernelGGL(update_kernel<float>, dim3(a.n_slots), dim3(UPD_THREADS), dyn, st, a);
   } else {
-    if (dyn > attr_f64) {
+    if (once_f64.need()) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&update_kernel<double>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)budget);
       if (e != hipSuccess) return e;
-      attr_f64 = budget;
     }
     hipLaunchKernelGGL(update_kernel<double>, dim3(a.n_slots), dim3(UPD_THREADS), dyn, st, a);
   }
@@ -1401,15 +1399,14 @@ hipError_t ls_ec_prepare_launch(const LsArgs &a, hipStream_t st) {
 hipError_t ls_ec_decide_launch(const LsArgs &a, hipStream_t st) {
   if (a.n_slots <= 0) return hipSuccess;
   const size_t dyn = (size_t)2 * CALS_RMAX * CALS_RMAX * sizeof(double);
-  static bool attr = false;
-  if (!attr) {
+  static AttrOnce once;
+  if (once.need()) {
     hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void *>(&ls_ec_decide_kernel<float>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
     hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void *>(&ls_ec_decide_kernel<double>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
     if (e1 != hipSuccess) return e1;
     if (e2 != hipSuccess) return e2;
-    attr = true;
   }
   if (a.dtype == CALS_F32)
     hipLaunchKernelGGL(ls_ec_decide_kernel<float>, dim3(a.n_slots), dim3(256), dyn, st, a);

@@ -347,13 +347,12 @@ int mttkrp_pick_mt(int m_tiles) {
 
 template <int MT, int VAR>
 static hipError_t launch_mt_var(int m_blocks, const MttkrpArgs &a, hipStream_t st) {
-  static bool attr_set = false;
-  if (!attr_set) {
+  static AttrOnce attr_once;
+  if (attr_once.need()) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&mttkrp_kernel<MT, VAR>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize,
                                        MtCfg<MT>::LDS_BYTES);
     if (e != hipSuccess) return e;
-    attr_set = true;
   }
   dim3 grid(a.grid, m_blocks, 1), block(512, 1, 1);
   hipLaunchKernelGGL((mttkrp_kernel<MT, VAR>), grid, block, MtCfg<MT>::LDS_BYTES, st, a);

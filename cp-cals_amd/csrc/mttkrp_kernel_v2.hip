@@ -260,15 +260,14 @@ __global__ void __launch_bounds__(256, 2) mttkrp2_kernel(const MttkrpArgs a) {
 
 template <int MT, bool EARLY>
 static hipError_t launch2_mt_e(const MttkrpArgs &a, hipStream_t st) {
-  static bool attr_set = false;
+  static AttrOnce attr_once;
   constexpr int lds_bytes = Mt2Cfg<MT>::LDS_BYTES > Mt2Cfg<(MT > 1 ? MT - 1 : 1)>::LDS_BYTES
                                 ? Mt2Cfg<MT>::LDS_BYTES
                                 : Mt2Cfg<(MT > 1 ? MT - 1 : 1)>::LDS_BYTES;
-  if (!attr_set) {
+  if (attr_once.need()) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&mttkrp2_kernel<MT, EARLY>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     if (e != hipSuccess) return e;
-    attr_set = true;
   }
   hipLaunchKernelGGL((mttkrp2_kernel<MT, EARLY>), dim3(a.grid), dim3(256), lds_bytes, st, a);
   return hipGetLastError();

@@ -322,13 +322,12 @@ __global__ void __launch_bounds__(512, 2) mttkrp3_kernel(const MttkrpArgs a) {
 
 template <int MT, typename T>
 static hipError_t launch3_mt(int m_blocks, const MttkrpArgs &a, hipStream_t st) {
-  static bool attr_set = false;
-  if (!attr_set) {
+  static AttrOnce attr_once;
+  if (attr_once.need()) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&mttkrp3_kernel<MT, T>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize,
                                        Mt3Cfg<MT, T>::LDS_BYTES);
     if (e != hipSuccess) return e;
-    attr_set = true;
   }
   dim3 grid(a.grid, m_blocks, 1), block(512, 1, 1);
   constexpr int lds_bytes = Mt3Cfg<MT, T>::LDS_BYTES;

@@ -346,14 +346,13 @@ hipError_t nnls_launch(const NnlsArgs &a_in, hipStream_t st) {
   // rows per workgroup: at least 4 per wave, enough workgroups to fill 256 CUs several times over
   int chunks = std::max(1, std::min((a.I + 4 * waves - 1) / (4 * waves), (4096 + a.n_slots - 1) / a.n_slots));
   a.chunks = chunks;
-  static size_t attr[2] = {0, 0};
+  static AttrOnce once[2];
   const int di = (a.dtype == CALS_F32) ? 1 : 0;
   const void *fn = di ? reinterpret_cast<const void *>(&nnls_kernel<float>)
                       : reinterpret_cast<const void *>(&nnls_kernel<double>);
-  if (dyn > attr[di]) {
+  if (once[di].need()) {
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)budget);
     if (e != hipSuccess) return e;
-    attr[di] = budget;
   }
   const dim3 grid((unsigned)(a.n_slots * chunks)), block(64 * waves);
   if (di)
