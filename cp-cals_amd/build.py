@@ -53,7 +53,7 @@ def build(force=False, verbose=False):
     api_src = os.path.join(HERE, "cals", "cals.cpp")
     api_lib = os.path.join(HERE, "libcals.so")
     if force or _newer(api_lib, [api_src, os.path.join(HERE, "cals", "cals.h"), LIB]):
-        cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-fPIC", "-shared", "-o", api_lib, api_src,
+        cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-fPIC", "-pthread", "-shared", "-o", api_lib, api_src,
                "-L" + HERE, "-lcals_hip", "-Wl,-rpath,$ORIGIN"]
         if verbose:
             print(" ".join(cmd))

@@ -2,8 +2,11 @@
 // body src/cals.cpp:19-395.
 #include "cals.h"
 
+#include <atomic>
 #include <chrono>
+#include <exception>
 #include <limits>
+#include <thread>
 
 #include "../../include/cals_hip.h"
 
@@ -20,8 +23,12 @@ void CalsParams::print() const {
   cout << "Buffer Size:     " << buffer_size << endl;
   cout << "Line Search:     " << (line_search ? "true" : "false") << endl;
   if (line_search) cout << "-Line Search Interval: " << line_search_interval << " iterations" << endl;
-  cout << "Device path:     MI355X HIP engine (device " << device << ", "
-       << (precision == FP32 ? "fp32" : "fp64") << " storage)" << endl;
+  cout << "Device path:     MI355X HIP engine (device";
+  if (devices.empty())
+    cout << " " << device;
+  else
+    for (int d : devices) cout << " " << d;
+  cout << ", " << (precision == FP32 ? "fp32" : "fp64") << " storage)" << endl;
   cout << "---------------------------------------" << endl;
 }
 
@@ -73,6 +80,101 @@ struct EngineGuard {
 }
 }  // namespace
 
+namespace {
+cals_hip_params to_hip_params(const CalsParams &p) {
+  cals_hip_params hp;
+  cals_hip_default_params(&hp);
+  hp.max_iterations = (int64_t)p.max_iterations;
+  hp.tol = p.tol;
+  hp.line_search = p.line_search ? 1 : 0;
+  hp.line_search_interval = p.line_search_interval;
+  hp.line_search_step = p.line_search_step;
+  hp.line_search_method = (int)p.line_search_method;
+  hp.force_max_iter = p.force_max_iter ? 1 : 0;
+  hp.always_evict_first = p.always_evict_first ? 1 : 0;
+  hp.update_method = (p.update_method == update::NNLS) ? 1 : 0;
+  return hp;
+}
+
+// CalsParams::devices with more than one entry: one engine (and one host thread) per device, each
+// with its own replica of X; the models sit behind one shared counter and a device claims a few
+// more whenever none of its claimed models is waiting for buffer columns (the pull-based hand-off
+// of cp-cals_amd/multi_gpu.py, here inside one process: no collective, nothing but indices shared).
+// Every model is fitted by exactly one device with the arithmetic of the single-device path.
+void cp_cals_devices(const Tensor &X, std::vector<std::reference_wrapper<Ktensor>> &all, const CalsParams &p,
+                     CalsReport &rep) {
+  const size_t n_dev = p.devices.size();
+  std::vector<int64_t> modes(X.get_modes().begin(), X.get_modes().end());
+  std::atomic<size_t> next{0};
+  std::vector<cals_hip_report> reports(n_dev);
+  std::vector<std::exception_ptr> errors(n_dev);
+  auto worker = [&](size_t d) {
+    try {
+      EngineGuard g;
+      int rc = cals_hip_create_ex(&g.e, (int)modes.size(), modes.data(), (int64_t)p.buffer_size, p.devices[d],
+                                  p.precision == CalsParams::FP32 ? CALS_HIP_F32 : CALS_HIP_F64);
+      if (rc) fail(g.e, "cals_hip_create", rc);
+      if ((rc = cals_hip_set_tensor(g.e, X.get_data()))) fail(g.e, "cals_hip_set_tensor", rc);
+      cals_hip_params hp = to_hip_params(p);
+      if ((rc = cals_hip_set_params(g.e, &hp))) fail(g.e, "cals_hip_set_params", rc);
+      std::vector<std::pair<size_t, int64_t>> mine;  // (index into all, ticket)
+      bool drained = false;
+      const size_t claim = (size_t)std::max(1, p.claim_models);
+      for (;;) {
+        if (!drained && cals_hip_queue_size(g.e) == 0) {
+          const size_t lo = next.fetch_add(claim);
+          if (lo >= all.size()) drained = true;
+          for (size_t i = lo; i < std::min(lo + claim, all.size()); i++) {
+            Ktensor &kt = all[i];
+            std::vector<double *> fptr;
+            for (auto &f : kt.get_factors()) fptr.push_back(f.get_data());
+            int64_t ticket = -1;
+            rc = cals_hip_enqueue(g.e, (int64_t)kt.get_components(), fptr.data(), kt.get_lambda().data(),
+                                  kt.is_jk() ? (int)kt.get_jk_mode() : -1, (int64_t)kt.get_jk_fiber(), &ticket);
+            if (rc) fail(g.e, "cals_hip_enqueue", rc);
+            mine.emplace_back(i, ticket);
+          }
+        }
+        if (cals_hip_queue_size(g.e) == 0 && cals_hip_models_in_flight(g.e) == 0) {
+          if (drained) break;
+          continue;
+        }
+        if ((rc = cals_hip_step(g.e, nullptr, nullptr))) fail(g.e, "cals_hip_step", rc);
+      }
+      for (auto &m : mine) {
+        cals_hip_model_status st;
+        if ((rc = cals_hip_model_result(g.e, m.second, &st))) fail(g.e, "cals_hip_model_result", rc);
+        Ktensor &kt = all[m.first];
+        kt.set_iters((dim_t)st.iters);
+        kt.set_approximation_error(st.approx_error);
+        kt.set_fit(st.fit, st.old_fit);
+      }
+      if ((rc = cals_hip_get_report(g.e, &reports[d]))) fail(g.e, "cals_hip_get_report", rc);
+    } catch (...) {
+      errors[d] = std::current_exception();
+      next.store(all.size());  // the other devices finish what they hold and stop claiming
+    }
+  };
+  std::vector<std::thread> threads;
+  for (size_t d = 0; d < n_dev; d++) threads.emplace_back(worker, d);
+  for (auto &t : threads) t.join();
+  for (auto &e : errors)
+    if (e) std::rethrow_exception(e);
+  rep.iter = 0;
+  rep.n_ktensors = 0;
+  rep.ktensor_comp_sum = 0;
+  rep.ls_performed = rep.ls_failed = 0;
+  for (auto &r : reports) {
+    rep.X_norm = r.X_norm;
+    rep.iter = std::max(rep.iter, (dim_t)r.iter);  // sweeps of the device that swept most
+    rep.n_ktensors += (int)r.n_ktensors;
+    rep.ktensor_comp_sum += (int)r.ktensor_comp_sum;
+    rep.ls_performed += (dim_t)r.ls_performed;
+    rep.ls_failed += (dim_t)r.ls_failed;
+  }
+}
+}  // namespace
+
 CalsReport cp_cals(const Tensor &X, KtensorQueue &kt_queue, CalsParams &p) {
   const auto t0 = std::chrono::steady_clock::now();
   if (!p.cuda)
@@ -92,23 +194,24 @@ CalsReport cp_cals(const Tensor &X, KtensorQueue &kt_queue, CalsParams &p) {
   rep.line_search_step = p.line_search_step;
   rep.line_search_method = p.line_search_method;
 
+  if (p.devices.size() > 1) {
+    std::vector<std::reference_wrapper<Ktensor>> all;
+    while (!kt_queue.empty()) {
+      all.push_back(kt_queue.front());
+      kt_queue.pop();
+    }
+    cp_cals_devices(X, all, p, rep);
+    rep.total_time = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return rep;
+  }
   std::vector<int64_t> modes(X.get_modes().begin(), X.get_modes().end());
   EngineGuard g;
-  int rc = cals_hip_create_ex(&g.e, (int)modes.size(), modes.data(), (int64_t)p.buffer_size, p.device,
+  int rc = cals_hip_create_ex(&g.e, (int)modes.size(), modes.data(), (int64_t)p.buffer_size,
+                              p.devices.size() == 1 ? p.devices[0] : p.device,
                               p.precision == CalsParams::FP32 ? CALS_HIP_F32 : CALS_HIP_F64);
   if (rc) fail(g.e, "cals_hip_create", rc);
   if ((rc = cals_hip_set_tensor(g.e, X.get_data()))) fail(g.e, "cals_hip_set_tensor", rc);
-  cals_hip_params hp;
-  cals_hip_default_params(&hp);
-  hp.max_iterations = (int64_t)p.max_iterations;
-  hp.tol = p.tol;
-  hp.line_search = p.line_search ? 1 : 0;
-  hp.line_search_interval = p.line_search_interval;
-  hp.line_search_step = p.line_search_step;
-  hp.line_search_method = (int)p.line_search_method;
-  hp.force_max_iter = p.force_max_iter ? 1 : 0;
-  hp.always_evict_first = p.always_evict_first ? 1 : 0;
-  hp.update_method = (p.update_method == update::NNLS) ? 1 : 0;
+  cals_hip_params hp = to_hip_params(p);
   if ((rc = cals_hip_set_params(g.e, &hp))) fail(g.e, "cals_hip_set_params", rc);
 
   std::vector<std::reference_wrapper<Ktensor>> kts;

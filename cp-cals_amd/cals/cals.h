@@ -356,6 +356,11 @@ struct CalsParams {
   bool force_max_iter{false};
   bool always_evict_first{false};
   int device{0};  // added: HIP device ordinal (default preserves single-GPU behaviour)
+  // added: more than one ordinal = one engine per listed device inside this process, the queue shared
+  // through an atomic counter (each model is fitted by exactly one device); claim_models = how many
+  // models a device takes at a time when none of its own is waiting for buffer columns
+  std::vector<int> devices{};
+  int claim_models{8};
   // added: storage/arithmetic type on the device, FP64 (the reference's) or FP32 (BASELINE config 4:
   // fp32 tensor copies, factors and MFMA; Gramians, solves, lambda, error stay fp64)
   enum PRECISION { FP64 = 0, FP32 = 1 };

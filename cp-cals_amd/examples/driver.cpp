@@ -26,6 +26,7 @@ static void split(const std::string &s, std::vector<dim_t> &out, char sep) {
 int main(int argc, char **argv) {
   std::vector<dim_t> modes = {210, 210, 210};
   int min_c = 1, max_c = 10, copies = 5, device = 0;
+  std::vector<int> devices;
   bool f32 = false;
   for (int i = 1; i < argc; ++i) {
     const std::string arg = argv[i];
@@ -54,6 +55,10 @@ int main(int argc, char **argv) {
       modes = v;
     } else if ((arg == "-d" || arg == "--device") && i + 1 < argc) {
       device = (int)std::strtol(argv[++i], nullptr, 10);
+    } else if (arg == "--devices" && i + 1 < argc) {  // e.g. 0,1,2,3: one engine per listed GPU, shared queue
+      std::vector<dim_t> v;
+      split(argv[++i], v, ',');
+      devices.assign(v.begin(), v.end());
     } else if ((arg == "-p" || arg == "--precision") && i + 1 < argc) {
       const std::string v = argv[++i];
       if (v != "f64" && v != "f32") {
@@ -84,6 +89,7 @@ int main(int argc, char **argv) {
   cp.max_iterations = 1000;
   cp.tol = 1e-5;
   cp.device = device;
+  cp.devices = devices;
   cp.precision = f32 ? cals::CalsParams::FP32 : cals::CalsParams::FP64;
   cp.buffer_size = std::accumulate(components.cbegin(), components.cend(), (dim_t)0);
   cp.print();

@@ -109,5 +109,46 @@ int main(int argc, char **argv) {
     threw = true;
   }
   printf("cuda=false throws: %d\n", (int)threw);
-  return (ok && threw) ? 0 : 1;
+  // CalsParams::devices: two engines (here on the same GPU, the box has one), one shared queue.  Every
+  // model is fitted by exactly one engine with the single-device arithmetic, so the per-model results
+  // must equal the oracle's again (same starting points: fresh copies of the initial factors).
+  double worst_md = 0.0;
+  int bad_md = 0, n_md = 0;
+  {
+    std::vector<cals::Ktensor> k2;
+    g_state = 0;  // the same stream again: P2 (discarded) and the same starting points
+    cals::Ktensor P2(10, modes);
+    P2.fill([]() { return next_pm1(); });
+    for (int r : ranks) {
+      k2.emplace_back((dim_t)r, modes);
+      k2.back().fill([]() { return next_pm1(); });
+    }
+    cals::CalsParams pm = prm;
+    pm.devices = {0, 0};
+    pm.claim_models = 3;
+    cals::KtensorQueue q3;
+    for (auto &k : k2) q3.emplace(k);
+    cals::CalsReport r3;
+    try {
+      r3 = cals::cp_cals(T, q3, pm);
+    } catch (const std::exception &e) {
+      fprintf(stderr, "cp_cals(devices) threw: %s\n", e.what());
+      return 3;
+    }
+    n_md = r3.n_ktensors;
+    for (size_t i = 0; i < k2.size(); i++) {
+      cals::Tensor a = k2[i].to_tensor();
+      std::vector<double> b(a.get_n_elements());
+      or_to_tensor(om[i].factors, om[i].lambda, 3, omodes, om[i].rank, b.data());
+      double d = 0.0;
+      for (dim_t e = 0; e < a.get_n_elements(); e++) d += (a[e] - b[e]) * (a[e] - b[e]);
+      d = std::sqrt(d);
+      if (d > worst_md) worst_md = d;
+      if ((int64_t)k2[i].get_iters() != om[i].iters) bad_md++;
+    }
+  }
+  printf("cp_cals with devices = {0, 0}: models %d, worst ||T_gpu - T_oracle|| = %.3e, iteration mismatches %d\n",
+         n_md, worst_md, bad_md);
+  const bool ok_md = worst_md <= 1e-9 && bad_md == 0 && n_md == (int)ranks.size();
+  return (ok && threw && ok_md) ? 0 : 1;
 }
