@@ -120,8 +120,19 @@ struct cals_hip_engine {
   size_t col_scratch_words = 0;
   int *d_colidx = nullptr;
   size_t colidx_cap = 0;
-  unsigned *h_stage = nullptr;
-  size_t h_stage_words = 0;
+  // pinned host arena for host -> device staging (index lists, admitted models): an allocation lives
+  // until the next reset, and resets happen where the stream is known to be idle (the per-sweep status
+  // read-back, cals_hip_synchronize), so no copy has to be waited for just to free its source
+  unsigned char *arena = nullptr;
+  size_t arena_cap = 0, arena_off = 0;
+  // evicted models on their way out: D2H into pinned h_out, scattered to the callers' storage later
+  // (while the next sweep runs), at the latest before the next eviction / before the API call returns
+  unsigned *h_out = nullptr;
+  size_t h_out_words = 0;
+  hipEvent_t ev_out = nullptr;
+  std::vector<int64_t> out_tickets;
+  std::vector<long long> out_off;  // scratch offsets per mode + lambda of the pending copy-out
+  int out_wpe = 2;
   void *partial = nullptr;
   size_t partial_elems = 0;
   void *krp_ws = nullptr;
@@ -301,15 +312,17 @@ void prof_collect(cals_hip_engine *e) {
   e->ev_used = 0;
 }
 
+int arena_alloc(cals_hip_engine *e, size_t bytes, void **out);
+
 int upload_slots(cals_hip_engine *e) {
   if (!e->slots_dirty) return CALS_HIP_OK;
-  std::vector<int> s;
-  s.reserve(e->registry.size());
-  for (auto t : e->registry) s.push_back(e->models[t].slot);
-  if (!s.empty()) {
-    HIPCHK(hipMemcpyAsync(e->d_slots, s.data(), s.size() * sizeof(int), hipMemcpyHostToDevice,
-                          e->stream));
-    HIPCHK(hipStreamSynchronize(e->stream));  // s is a temporary
+  if (!e->registry.empty()) {
+    int *s = nullptr;
+    int rc = arena_alloc(e, e->registry.size() * sizeof(int), (void **)&s);
+    if (rc) return rc;
+    size_t k = 0;
+    for (auto t : e->registry) s[k++] = e->models[t].slot;
+    HIPCHK(hipMemcpyAsync(e->d_slots, s, k * sizeof(int), hipMemcpyHostToDevice, e->stream));
   }
   e->slots_dirty = false;
   return CALS_HIP_OK;
@@ -777,6 +790,7 @@ int fetch_status(cals_hip_engine *e) {
   HIPCHK(hipMemcpyAsync(e->h_status, e->d_status, (ns + 1) * sizeof(StatusRec), hipMemcpyDeviceToHost,
                         e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
+  e->arena_off = 0;  // the stream is idle: every staged copy has been consumed
   if (e->changed_deferred) {
     if (e->h_status[0].flags) tree_invalidate(e);
     e->changed_deferred = false;
@@ -796,8 +810,8 @@ int fetch_status(cals_hip_engine *e) {
 
 // MultiKtensor::remove + Ktensor::detach (multi_ktensor.cpp:132-163, ktensor.cpp:127-135):
 // copy the models' columns back to the callers, zero them on the device, free the columns.
-// device scratch for n_cols columns of `words_per_col` 4-byte words in total, index lists of n_idx ints
-int ensure_col_scratch(cals_hip_engine *e, size_t words, size_t n_idx, bool host_too) {
+// device scratch of `words` 4-byte words and index lists of n_idx ints
+int ensure_col_scratch(cals_hip_engine *e, size_t words, size_t n_idx) {
   if (words > e->col_scratch_words) {
     if (e->col_scratch) HIPCHK(hipFree(e->col_scratch));
     e->col_scratch = nullptr;
@@ -810,12 +824,49 @@ int ensure_col_scratch(cals_hip_engine *e, size_t words, size_t n_idx, bool host
     e->colidx_cap = std::max<size_t>(2 * n_idx, 4096);
     HIPCHK(hipMalloc((void **)&e->d_colidx, e->colidx_cap * sizeof(int)));
   }
-  if (host_too && words > e->h_stage_words) {
-    if (e->h_stage) HIPCHK(hipHostFree(e->h_stage));
-    e->h_stage = nullptr;
-    e->h_stage_words = words + words / 2;
-    HIPCHK(hipHostMalloc((void **)&e->h_stage, e->h_stage_words * sizeof(unsigned), hipHostMallocDefault));
+  return CALS_HIP_OK;
+}
+
+// `bytes` of pinned host memory, valid until the next arena reset.  Growing waits for the stream first
+// (every earlier allocation has then been consumed: callers enqueue their copy right after filling it).
+int arena_alloc(cals_hip_engine *e, size_t bytes, void **out) {
+  bytes = (bytes + 63) / 64 * 64;
+  if (e->arena_off + bytes > e->arena_cap) {
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if (e->arena) HIPCHK(hipHostFree(e->arena));
+    e->arena = nullptr;
+    e->arena_cap = std::max<size_t>(2 * e->arena_cap, bytes + (1u << 20));
+    HIPCHK(hipHostMalloc((void **)&e->arena, e->arena_cap, hipHostMallocDefault));
+    e->arena_off = 0;
   }
+  *out = e->arena + e->arena_off;
+  e->arena_off += bytes;
+  return CALS_HIP_OK;
+}
+
+// evicted models whose factors are still in h_out: wait for the D2H, scatter into the callers' storage
+int flush_pending_out(cals_hip_engine *e) {
+  if (e->out_tickets.empty()) return CALS_HIP_OK;
+  HIPCHK(hipEventSynchronize(e->ev_out));
+  size_t k0 = 0;  // first staged column of the model
+  const int wpe = e->out_wpe;
+  for (auto t : e->out_tickets) {
+    HostModel &m = e->models[t];
+    for (int n = 0; n < e->n_modes; n++) {
+      const size_t cnt = (size_t)(e->modes[n] * m.rank);
+      const unsigned *src = e->h_out + e->out_off[n] + (size_t)e->modes[n] * wpe * k0;
+      if (e->dtype == CALS_F32) {
+        const float *f = reinterpret_cast<const float *>(src);
+        for (size_t i = 0; i < cnt; i++) m.factors[n][i] = (double)f[i];
+      } else {
+        std::memcpy(m.factors[n], src, cnt * sizeof(double));
+      }
+    }
+    std::memcpy(m.lambda, e->h_out + e->out_off[e->n_modes] + 2 * k0, sizeof(double) * (size_t)m.rank);
+    m.st.evicted = 1;
+    k0 += (size_t)m.rank;
+  }
+  e->out_tickets.clear();
   return CALS_HIP_OK;
 }
 
@@ -846,42 +897,38 @@ int remove_models(cals_hip_engine *e, std::vector<int64_t> rm) {
   words += 2 * nc;
   a.n_bufs = e->n_modes + 1;
   a.zero_src_bufs = e->n_modes;  // lambda is left as it is, as before
-  int rc = ensure_col_scratch(e, words, nc, true);
+  int rc = flush_pending_out(e);  // h_out is about to be reused
   if (rc) return rc;
-  HIPCHK(hipMemcpyAsync(e->d_colidx, cols.data(), nc * sizeof(int), hipMemcpyHostToDevice, e->stream));
+  if ((rc = ensure_col_scratch(e, words, nc))) return rc;
+  if (words > e->h_out_words) {
+    if (e->h_out) HIPCHK(hipHostFree(e->h_out));
+    e->h_out = nullptr;
+    e->h_out_words = words + words / 2;
+    HIPCHK(hipHostMalloc((void **)&e->h_out, e->h_out_words * sizeof(unsigned), hipHostMallocDefault));
+  }
+  if (!e->ev_out) HIPCHK(hipEventCreateWithFlags(&e->ev_out, hipEventDisableTiming));
+  int *h_cols = nullptr;
+  if ((rc = arena_alloc(e, nc * sizeof(int), (void **)&h_cols))) return rc;
+  std::memcpy(h_cols, cols.data(), nc * sizeof(int));
+  HIPCHK(hipMemcpyAsync(e->d_colidx, h_cols, nc * sizeof(int), hipMemcpyHostToDevice, e->stream));
   a.src = e->d_colidx;
   a.dst = e->d_colidx;
   a.n_cols = (int)nc;
   a.scratch = e->col_scratch;
   HIPCHK(gather_columns_launch(a, e->stream));
-  HIPCHK(hipMemcpyAsync(e->h_stage, e->col_scratch, words * sizeof(unsigned), hipMemcpyDeviceToHost, e->stream));
-  HIPCHK(hipStreamSynchronize(e->stream));
-  {
-    size_t k0 = 0;  // first staged column of the model
-    for (auto t : rm) {
-      HostModel &m = e->models[t];
-      for (int n = 0; n < e->n_modes; n++) {
-        const size_t cnt = (size_t)(e->modes[n] * m.rank);
-        const unsigned *src = e->h_stage + a.scratch_off[n] + (size_t)e->modes[n] * wpe * k0;
-        if (e->dtype == CALS_F32) {
-          const float *f = reinterpret_cast<const float *>(src);
-          for (size_t i = 0; i < cnt; i++) m.factors[n][i] = (double)f[i];
-        } else {
-          std::memcpy(m.factors[n], src, cnt * sizeof(double));
-        }
-      }
-      std::memcpy(m.lambda, e->h_stage + a.scratch_off[e->n_modes] + 2 * k0, sizeof(double) * (size_t)m.rank);
-      k0 += (size_t)m.rank;
-    }
-  }
+  HIPCHK(hipMemcpyAsync(e->h_out, e->col_scratch, words * sizeof(unsigned), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipEventRecord(e->ev_out, e->stream));
+  // the host-side scatter into the callers' storage is deferred (flush_pending_out)
+  e->out_tickets.assign(rm.begin(), rm.end());
+  e->out_off.assign(a.scratch_off, a.scratch_off + e->n_modes + 1);
+  e->out_wpe = wpe;
   for (auto ticket : rm) {
     HostModel &m = e->models[ticket];
     m.st.iters = e->h_iters[m.slot];
     m.st.approx_error = e->h_err[m.slot];
     m.st.fit = e->h_fit[m.slot];
     m.st.old_fit = e->h_old_fit[m.slot];
-    m.st.evicted = 1;
-    m.state = 2;
+    m.state = 2;  // st.evicted is set once the factors have landed in the caller's storage
     for (int64_t c = m.col; c < m.col + m.rank; c++) e->occ[(size_t)c] = 0;
     e->free_slots.push_back(m.slot);
     e->registry.erase(std::find(e->registry.begin(), e->registry.end(), ticket));
@@ -947,12 +994,15 @@ int compress(cals_hip_engine *e) {
       add(e->prev_lambda, 1, 2);
       add(e->backup_lambda, 1, 2);
     }
-    int rc = ensure_col_scratch(e, words, 2 * nc + pairs.size(), false);
+    int rc = ensure_col_scratch(e, words, 2 * nc + pairs.size());
     if (rc) return rc;
-    std::vector<int> idx(src);
-    idx.insert(idx.end(), dst.begin(), dst.end());
-    idx.insert(idx.end(), pairs.begin(), pairs.end());
-    HIPCHK(hipMemcpyAsync(e->d_colidx, idx.data(), idx.size() * sizeof(int), hipMemcpyHostToDevice, e->stream));
+    int *idx = nullptr;
+    const size_t n_idx = 2 * nc + pairs.size();
+    if ((rc = arena_alloc(e, n_idx * sizeof(int), (void **)&idx))) return rc;
+    std::memcpy(idx, src.data(), nc * sizeof(int));
+    std::memcpy(idx + nc, dst.data(), nc * sizeof(int));
+    std::memcpy(idx + 2 * nc, pairs.data(), pairs.size() * sizeof(int));
+    HIPCHK(hipMemcpyAsync(e->d_colidx, idx, n_idx * sizeof(int), hipMemcpyHostToDevice, e->stream));
     a.src = e->d_colidx;
     a.dst = e->d_colidx + nc;
     a.n_cols = (int)nc;
@@ -960,7 +1010,6 @@ int compress(cals_hip_engine *e) {
     HIPCHK(gather_columns_launch(a, e->stream));
     HIPCHK(scatter_columns_launch(a, e->stream));
     HIPCHK(set_cols_launch(e->d_colidx + 2 * nc, (int)(pairs.size() / 2), e->mt.col, e->stream));
-    HIPCHK(hipStreamSynchronize(e->stream));  // idx is a temporary
   }
   adjust_edges(e);
   return CALS_HIP_OK;
@@ -1017,17 +1066,24 @@ int admit(cals_hip_engine *e, int64_t *n_admitted) {
     ca.scratch_off[e->n_modes] = (long long)words;
     words += 2 * nc;
     ca.n_bufs = e->n_modes + 1;
+    const size_t n_idx = nc + desc.size() + new_slots.size();
+    unsigned *h_in = nullptr;  // [data words][column list | slot descriptors | new slots]
     {
-      int rc = ensure_col_scratch(e, words, nc + desc.size() + new_slots.size(), true);
+      int rc = ensure_col_scratch(e, words, n_idx);
       if (rc) return rc;
+      if ((rc = arena_alloc(e, words * sizeof(unsigned) + n_idx * sizeof(int), (void **)&h_in))) return rc;
     }
+    int *h_idx = reinterpret_cast<int *>(h_in + words);
+    std::memcpy(h_idx, cols.data(), nc * sizeof(int));
+    std::memcpy(h_idx + nc, desc.data(), desc.size() * sizeof(int));
+    std::memcpy(h_idx + nc + desc.size(), new_slots.data(), new_slots.size() * sizeof(int));
     {
       size_t k0 = 0;
       for (auto t : admitted) {
         const HostModel &m = e->models[t];
         for (int n = 0; n < e->n_modes; n++) {
           const size_t cnt = (size_t)(e->modes[n] * m.rank);
-          unsigned *dst = e->h_stage + ca.scratch_off[n] + (size_t)e->modes[n] * wpe * k0;
+          unsigned *dst = h_in + ca.scratch_off[n] + (size_t)e->modes[n] * wpe * k0;
           if (e->dtype == CALS_F32) {  // fp32 storage: the callers' fp64 factors are rounded once, on admission
             float *f = reinterpret_cast<float *>(dst);
             for (size_t i = 0; i < cnt; i++) f[i] = (float)m.factors[n][i];
@@ -1035,12 +1091,12 @@ int admit(cals_hip_engine *e, int64_t *n_admitted) {
             std::memcpy(dst, m.factors[n], cnt * sizeof(double));
           }
         }
-        std::memcpy(e->h_stage + ca.scratch_off[e->n_modes] + 2 * k0, m.lambda, sizeof(double) * (size_t)m.rank);
+        std::memcpy(h_in + ca.scratch_off[e->n_modes] + 2 * k0, m.lambda, sizeof(double) * (size_t)m.rank);
         k0 += (size_t)m.rank;
       }
     }
-    HIPCHK(hipMemcpyAsync(e->col_scratch, e->h_stage, words * sizeof(unsigned), hipMemcpyHostToDevice, e->stream));
-    HIPCHK(hipMemcpyAsync(e->d_colidx, cols.data(), nc * sizeof(int), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(e->col_scratch, h_in, words * sizeof(unsigned), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(e->d_colidx, h_idx, n_idx * sizeof(int), hipMemcpyHostToDevice, e->stream));
     ca.src = e->d_colidx;
     ca.dst = e->d_colidx;
     ca.n_cols = (int)nc;
@@ -1048,10 +1104,6 @@ int admit(cals_hip_engine *e, int64_t *n_admitted) {
     HIPCHK(scatter_columns_launch(ca, e->stream));
     // per-slot scalars + Gramians of the new models, all modes (multi_ktensor.cpp:88-96)
     int *d_desc = e->d_colidx + nc, *d_new = d_desc + desc.size();  // behind the column list
-    HIPCHK(hipMemcpyAsync(d_desc, desc.data(), desc.size() * sizeof(int), hipMemcpyHostToDevice,
-                          e->stream));
-    HIPCHK(hipMemcpyAsync(d_new, new_slots.data(), new_slots.size() * sizeof(int),
-                          hipMemcpyHostToDevice, e->stream));
     HIPCHK(init_slots_launch(d_desc, (int)new_slots.size(), e->mt, e->stream));
     if (e->prm.update_method == 1) {
       int rc2 = alloc_nnls(e);
@@ -1076,7 +1128,6 @@ int admit(cals_hip_engine *e, int64_t *n_admitted) {
     g.n_modes = e->n_modes;
     g.dtype = e->dtype;
     HIPCHK(gram_init_launch(g, e->stream));
-    HIPCHK(hipStreamSynchronize(e->stream));  // cols / desc / new_slots are temporaries
   }
   if (n_admitted) *n_admitted = count;
   return CALS_HIP_OK;
@@ -1370,7 +1421,9 @@ int cals_hip_destroy(cals_hip_engine *e) {
   fr(e->d_nnls_status);
   fr(e->col_scratch);
   fr(e->d_colidx);
-  if (e->h_stage) (void)hipHostFree(e->h_stage);
+  if (e->arena) (void)hipHostFree(e->arena);
+  if (e->h_out) (void)hipHostFree(e->h_out);
+  if (e->ev_out) (void)hipEventDestroy(e->ev_out);
   fr(e->partial);
   fr(e->tree.Tbuf);
   fr(e->tree.Pt);
@@ -1544,7 +1597,8 @@ int cals_hip_evict(cals_hip_engine *e, int64_t *n_evicted) {
   HIPCHK(hipSetDevice(e->device));  // a process may hold engines on several GPUs
   int rc = fetch_status(e);
   if (rc) return rc;
-  return evict(e, n_evicted);
+  if ((rc = evict(e, n_evicted))) return rc;
+  return flush_pending_out(e);  // the callers' storage is complete when this call returns
 }
 
 // One iteration of cals_hip_run's loop (src/cals.cpp:182-362): admit what fits, one sweep with the
@@ -1560,6 +1614,9 @@ int cals_hip_step(cals_hip_engine *e, int64_t *n_admitted, int64_t *n_evicted) {
   int rc = admit(e, n_admitted);
   if (rc) return rc;
   if ((rc = sweep_once(e, true, true))) return rc;
+  // models evicted by the previous step land in their callers' storage while this sweep runs; the
+  // ones evicted by this step follow at the next step, cals_hip_model_result or cals_hip_synchronize
+  if ((rc = flush_pending_out(e))) return rc;
   if ((rc = fetch_status(e))) return rc;
   if (e->prm.line_search)
     for (auto t : e->registry) {
@@ -1612,6 +1669,8 @@ int cals_hip_run(cals_hip_engine *e, cals_hip_report *rep) {
     if (rc) return rc;
     lap(0);
     if ((rc = sweep_once(e, true, true))) return rc;
+    // the models evicted after the previous sweep reach their callers' storage while this one runs
+    if ((rc = flush_pending_out(e))) return rc;
     lap(1);
     if ((rc = fetch_status(e))) return rc;
     lap(2);
@@ -1625,7 +1684,12 @@ int cals_hip_run(cals_hip_engine *e, cals_hip_report *rep) {
     lap(3);
     converged = e->queue.empty() && e->registry.empty();
   }
+  {
+    int rc = flush_pending_out(e);
+    if (rc) return rc;
+  }
   HIPCHK(hipStreamSynchronize(e->stream));
+  e->arena_off = 0;
   const double t1 = now_ms();
   if (timing)
     fprintf(stderr, "cals_hip_run: %lld sweeps; admit %.1f ms, sweep %.1f ms, status %.1f ms, evict+compress %.1f ms\n",
@@ -1646,6 +1710,12 @@ int cals_hip_run(cals_hip_engine *e, cals_hip_report *rep) {
 
 int cals_hip_model_result(const cals_hip_engine *e, int64_t ticket, cals_hip_model_status *st) {
   if (!e || !st || ticket < 0 || ticket >= (int64_t)e->models.size()) return CALS_HIP_ERR_ARG;
+  if (!e->out_tickets.empty()) {  // an evicted model's factors may still be on their way out
+    cals_hip_engine *m = const_cast<cals_hip_engine *>(e);
+    (void)hipSetDevice(m->device);
+    int rc = flush_pending_out(m);
+    if (rc) return rc;
+  }
   *st = e->models[(size_t)ticket].st;
   return CALS_HIP_OK;
 }
@@ -1657,7 +1727,10 @@ int64_t cals_hip_queue_size(const cals_hip_engine *e) { return e ? (int64_t)e->q
 int cals_hip_synchronize(cals_hip_engine *e) {
   if (!e) return CALS_HIP_ERR_ARG;
   HIPCHK(hipSetDevice(e->device));  // a process may hold engines on several GPUs
+  int rc = flush_pending_out(e);
+  if (rc) return rc;
   HIPCHK(hipStreamSynchronize(e->stream));
+  e->arena_off = 0;
   return CALS_HIP_OK;
 }
 
