@@ -148,6 +148,10 @@ int cals_hip_enqueue(cals_hip_engine *e, int64_t rank, double *const *factors, d
  * update, error, line search, eviction, compress, until queue and registry are empty. */
 int cals_hip_run(cals_hip_engine *e, cals_hip_report *rep);
 
+/* Per-model results.  st->evicted = 1 means the model's factors and lambda are complete in the caller's
+ * storage: an evicted model's data leaves the device asynchronously (it is scattered into the caller's
+ * buffers while the next sweep runs) and this call, cals_hip_run, cals_hip_evict and
+ * cals_hip_synchronize complete any transfer still pending before they return. */
 int cals_hip_model_result(const cals_hip_engine *e, int64_t ticket, cals_hip_model_status *st);
 
 /* ---- step-wise control (what cals_hip_run is made of; used by bench.py and the tests) ---- */
@@ -165,6 +169,8 @@ int cals_hip_evict(cals_hip_engine *e, int64_t *n_evicted);
  * runs (work-queue hand-off between GPUs, cp-cals_amd/multi_gpu.py).  No-op when nothing is queued
  * or in flight.  cals_hip_get_report: the counters of cals_hip_report accumulated so far (iter =
  * sweeps done by this engine, times 0). */
+/* (The factors of the models a step evicts reach the callers' storage during the NEXT step -- or at
+ * cals_hip_model_result / cals_hip_synchronize, whichever comes first.) */
 int cals_hip_step(cals_hip_engine *e, int64_t *n_admitted, int64_t *n_evicted);
 int cals_hip_get_report(const cals_hip_engine *e, cals_hip_report *rep);
 int64_t cals_hip_active_cols(const cals_hip_engine *e);  /* mkt.get_factor(0).get_cols() */
