@@ -658,7 +658,11 @@ int sweep_once(cals_hip_engine *e, bool evict_enabled, bool defer_changed = fals
     if (by_contract) {
       if ((rc = launch_contract(e, R, e->factor[n]))) return rc;
       tree_invalidate(e);  // T is consumed: mode a of the pair is updated next
-    } else if (e->tree.on && e->tree.pair[n].on) {
+    } else if (e->tree.on && e->tree.pair[n].on &&
+               !(e->tree.kind == 3 && n == e->n_modes - 1 && evict_enabled && !e->queue.empty())) {
+      // (Plan M's last pair hands its T over the sweep boundary.  While models are waiting in the
+      // queue the column layout changes after nearly every sweep -- eviction, compress, admission --
+      // and that T would be dropped unused: the plain fused MTTKRP is the cheaper way to G then.)
       if ((rc = launch_ttm(e, n, R, &g))) return rc;
     } else if ((rc = launch_mttkrp(e, n, R, &g))) {
       return rc;
