@@ -5,7 +5,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcals_hip.so")
-SOURCES = ["mttkrp_kernel.hip", "mttkrp_kernel_v2.hip", "mttkrp_kernel_v3.hip", "ttm_kernel.hip", "model_kernels.hip", "nnls_kernel.hip", "cals_hip_engine.cpp"]
+SOURCES = ["mttkrp_kernel_v3.hip", "ttm_kernel.hip", "model_kernels.hip", "nnls_kernel.hip", "cals_hip_engine.cpp"]
 HEADERS = ["cals_hip_internal.h", "mfma_common.h", os.path.join("..", "..", "include", "cals_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-Wall", "-Wno-unused-result"]
 

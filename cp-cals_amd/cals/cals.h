@@ -425,13 +425,13 @@ void generate_jk_ktensors(Ktensor const &reference_ktensor, vector<Ktensor> &jk_
 void jk_permutation_adjustment(Ktensor &ktensor, vector<Ktensor> &jk_ktensor_v);
 }  // namespace utils
 
-// Linear sum assignment on an n x n col-major cost matrix (what the reference gets from SciPy's
-// rectangular_lsap, extern/rectangular_lsap): col_of_row[i] = column assigned to row i.
-// Own implementation (Hungarian / Kuhn-Munkres with potentials), returns 0 on success.
+// Linear sum assignment on an n x n COLUMN-major cost matrix: col_of_row[i] = column assigned to row i
+// (convenience over solve_rectangular_linear_sum_assignment below, which reads row-major).
 int solve_linear_sum_assignment(int n, const double *cost_colmajor, bool maximize, int64_t *col_of_row);
 }  // namespace cals
-// extern/rectangular_lsap/rectangular_lsap.h:44 (the MEX front-ends call it directly): row-major nr x nc
-// cost, a = row indices, b = assigned columns.  Square problems only (all the reference's call sites).
+// extern/rectangular_lsap/rectangular_lsap.h:44 (utils.cpp:79 and the MEX front-ends call it directly):
+// ROW-major nr x nc cost, any shape; (a[k], b[k]) = assigned (row, column) pairs sorted by row.  Own
+// implementation of the same algorithm (Crouse's shortest augmenting paths) with the same tie rules.
 extern "C" int solve_rectangular_linear_sum_assignment(intptr_t nr, intptr_t nc, double *input_cost,
                                                         bool maximize, int64_t *a, int64_t *b);
 namespace cals {

@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <mutex>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -44,8 +45,7 @@ struct ModeLayout {
   int A = 0, Ap = 0, Mp = 0;
   long long S = 1;
   void *Xp = nullptr;  // storage dtype of the engine
-  int MT = 0, m_blocks = 1, ldPart = 0;        // v1 tiling (8 waves, one workgroup per CU)
-  int MT2 = 0, m_blocks2 = 1, k_big2 = 0;      // v2 tiling (two 4-wave workgroups per CU)
+  int MT = 0, m_blocks = 1, ldPart = 0;        // fused-MTTKRP tiling (8 waves, one workgroup per CU)
 };
 
 // Dimension-tree plans for 3-way tensors (ttm_kernel.hip).  pair[n]: modes n ("first") and
@@ -87,7 +87,6 @@ struct cals_hip_engine {
   int64_t buffer = 0;
   int device = 0;
   int n_cu = 256;
-  int mttkrp_kernel = 4;  // CALS_MTTKRP_KERNEL: 4 = v3 schedule (default), 1 = v1, 2/3 = v2 tilings
   hipStream_t stream = nullptr;
   std::string err;
   cals_hip_params prm{};
@@ -196,6 +195,25 @@ int fail(cals_hip_engine *e, int code, const std::string &msg) {
   } while (0)
 
 int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// Process exit: the HIP/HSA runtimes tear their state down from exit handlers that they register when
+// the first HIP call initialises them.  This handler is registered AFTER that (at the first successful
+// engine creation), so it runs BEFORE theirs: every device an engine ever used is drained while the
+// runtime is still whole, and nothing of ours (a kernel tail, a pinned-memory copy, an event) can be in
+// flight on the runtime's helper threads when its globals go away.
+std::atomic<unsigned long long> g_devices_used{0};
+void drain_devices_at_exit() {
+  const unsigned long long used = g_devices_used.load();
+  for (int d = 0; d < 64; d++)
+    if (used & (1ull << d)) {
+      if (hipSetDevice(d) == hipSuccess) (void)hipDeviceSynchronize();
+    }
+}
+void note_device_used(int device) {
+  static std::once_flag once;
+  g_devices_used.fetch_or(1ull << (device & 63));
+  std::call_once(once, [] { std::atexit(drain_devices_at_exit); });
+}
 
 template <typename T>
 int dev_alloc(cals_hip_engine *e, T **p, size_t n) {
@@ -401,12 +419,10 @@ Geo geometry(const cals_hip_engine *e, int mode, int64_t R) {
   Geo g;
   g.NB = (int)((R + CALS_BN - 1) / CALS_BN);
   const long long U = (long long)(L.Ap / 16) * L.S;
-  long long T = (e->mttkrp_kernel == 3)   ? (2 * e->n_cu) / std::max(1, g.NB)
-                : (e->mttkrp_kernel == 2) ? (2 * e->n_cu) / std::max(1, g.NB * L.m_blocks2)
-                                          : e->n_cu / std::max(1, g.NB * L.m_blocks);
+  long long T = e->n_cu / std::max(1, g.NB * L.m_blocks);
   if (T < 1) T = 1;
   if (T > U) T = U;
-  if (e->mttkrp_kernel == 4 && (long long)g.NB * L.m_blocks > e->n_cu / 2) {
+  if ((long long)g.NB * L.m_blocks > e->n_cu / 2) {
     // many column blocks: several rounds of finer workgroups (see pick_team); unit = 16 rows of the
     // inner mode for one s, overhead ~ 1 % of a column block's units
     const size_t nb_max = (size_t)((e->buffer + CALS_BN - 1) / CALS_BN);
@@ -469,23 +485,12 @@ int launch_mttkrp(cals_hip_engine *e, int mode, int64_t R, Geo *geo_out, void *c
   a.dbg_no_stagger = getenv("CALS_MTTKRP_NO_STAGGER") ? 1 : 0;
   a.dbg_no_barrier = getenv("CALS_MTTKRP_NO_BARRIER") ? 1 : 0;
   a.dbg_prio = getenv("CALS_MTTKRP_PRIO") ? atoi(getenv("CALS_MTTKRP_PRIO")) : 0;
-  if (e->mttkrp_kernel == 2 || e->mttkrp_kernel == 3) {
-    a.m_blocks = L.m_blocks2;
-    a.k_big = L.k_big2;
-    a.loop_mblocks = (e->mttkrp_kernel == 3) ? 1 : 0;
-    a.grid = a.loop_mblocks ? g.NB * g.T : g.NB * g.T * L.m_blocks2;
-  }
   if ((size_t)g.NB * g.T * (size_t)L.ldPart * CALS_BN > e->partial_elems)
     return fail(e, CALS_HIP_ERR_STATE, "internal: partial buffer too small");
   double total = 1.0;
   for (int n = 0; n < e->n_modes; n++) total *= (double)e->modes[n];
   const int pk = prof_begin(e, 0, 2.0 * total * (double)R);
-  if (e->mttkrp_kernel == 4)
-    HIPCHK(mttkrp3_launch(L.MT, L.m_blocks, a, e->stream));
-  else if (e->mttkrp_kernel >= 2)
-    HIPCHK(mttkrp2_launch(L.MT2, a, e->stream));
-  else
-    HIPCHK(mttkrp_launch(L.MT, L.m_blocks, a, e->stream));
+  HIPCHK(mttkrp3_launch(L.MT, L.m_blocks, a, e->stream));
   prof_end(e, pk);
   if (geo_out) *geo_out = g;
   return CALS_HIP_OK;
@@ -1277,9 +1282,14 @@ int cals_hip_create_ex(cals_hip_engine **out, int n_modes, const int64_t *modes,
         tp.pair[n].on = (choice == 3) || (choice == 1 && n == 0) || (choice == 2 && n == 1);
         if (tp.pair[n].on) need = std::max(need, t_bytes(n));
       }
+      // The plan must depend on the problem and the device only -- never on what else happens to
+      // occupy the GPU (other ranks' engines, other processes): different plans associate the same
+      // sums differently, and under tolerance-driven eviction that could change iteration counts
+      // between otherwise identical runs.  T may take up to 40 % of the device's TOTAL memory; if it
+      // then cannot be allocated, create fails loudly (below) instead of switching plans.
       size_t free_b = 0, total_b = 0;
       HIPCHK(hipMemGetInfo(&free_b, &total_b));
-      tp.on = need < free_b / 3;  // T must leave room for the X copies and the model state
+      tp.on = (double)need < 0.4 * (double)total_b;
       if (tp.on) {
         tp.kind = choice;
       } else {
@@ -1309,9 +1319,6 @@ int cals_hip_create_ex(cals_hip_engine **out, int n_modes, const int64_t *modes,
     L.MT = mttkrp_pick_mt((m_tiles + L.m_blocks - 1) / L.m_blocks);
     if (L.MT == 0) return fail(e, CALS_HIP_ERR_ARG, "internal: no MTTKRP tile for this mode size");
     L.ldPart = L.m_blocks * 16 * L.MT;
-    L.m_blocks2 = (m_tiles + 9) / 10;
-    L.MT2 = (m_tiles + L.m_blocks2 - 1) / L.m_blocks2;
-    L.k_big2 = m_tiles - L.m_blocks2 * (L.MT2 - 1);
     part_rows_max = std::max<size_t>(part_rows_max, (size_t)L.ldPart * (size_t)L.m_blocks);
     if (L.s_modes.size() > 1) krp_max = std::max<size_t>(krp_max, (size_t)L.S * (size_t)buffer_size);
   }
@@ -1340,12 +1347,13 @@ int cals_hip_create_ex(cals_hip_engine **out, int n_modes, const int64_t *modes,
     }
     if ((rc = dev_alloc_elems(e, &tp.Pt, pt_elems))) return rc;
     if (hipMalloc(&tp.Tbuf, t_elems * e->es) != hipSuccess) {
-      // no room for T after all: run the three fused MTTKRPs (they work with any inner mode)
       (void)hipGetLastError();
       tp.Tbuf = nullptr;
-      tp.on = false;
-      tp.kind = 0;
-      for (int n = 0; n < 3; n++) tp.pair[n].on = false;
+      return fail(e, CALS_HIP_ERR_HIP,
+                  "cannot allocate the dimension-tree buffer T (" + std::to_string(t_elems * e->es >> 20) +
+                      " MiB): the device is short of free memory.  The MTTKRP plan is fixed by the problem "
+                      "size, not by the memory left over; free the device or set CALS_HIP_TREE=0 "
+                      "(three fused MTTKRPs per sweep, no T)");
     }
   }
   size_t ld_max = 0;
@@ -1357,11 +1365,6 @@ int cals_hip_create_ex(cals_hip_engine **out, int n_modes, const int64_t *modes,
   if (getenv("CALS_MTTKRP_CLOCK")) {
     if ((rc = dev_alloc(e, &e->dbg_clock, (size_t)16384))) return rc;
   }
-  if (const char *k = getenv("CALS_MTTKRP_KERNEL")) {
-    const int v = atoi(k);
-    e->mttkrp_kernel = (v >= 2 && v <= 4) ? v : 1;
-  }
-  if (e->dtype == CALS_F32) e->mttkrp_kernel = 4;  // the fp32 MTTKRP exists in the v3 schedule only
   (void)part_rows_max;
   if ((rc = dev_alloc_elems(e, &e->partial, e->partial_elems))) return rc;
   if (krp_max) {
@@ -1397,12 +1400,15 @@ int cals_hip_create_ex(cals_hip_engine **out, int n_modes, const int64_t *modes,
   e->occ.assign((size_t)buffer_size, 0);
   adjust_edges(e);
   HIPCHK(hipStreamSynchronize(e->stream));
+  note_device_used(device);
   return CALS_HIP_OK;
 }
 
 int cals_hip_destroy(cals_hip_engine *e) {
   if (!e) return CALS_HIP_OK;
-  HIPCHK(hipSetDevice(e->device));  // a process may hold engines on several GPUs
+  // Everything is released whatever a HIP call returns on the way (an engine whose create failed
+  // half-way, or whose device is gone, must not leak the rest or its host side).
+  (void)hipSetDevice(e->device);  // a process may hold engines on several GPUs
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   auto fr = [](void *p) {
     if (p) (void)hipFree(p);
@@ -1435,6 +1441,7 @@ int cals_hip_destroy(cals_hip_engine *e) {
   fr(e->d_status);
   if (e->h_status) (void)hipHostFree(e->h_status);
   fr(e->dbg_trace);
+  fr(e->dbg_clock);
   fr(e->krp_ws);
   fr(e->d_jk_norms);
   fr(e->mt.col);

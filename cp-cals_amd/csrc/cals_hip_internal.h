@@ -6,6 +6,7 @@
 #include <stdint.h>
 
 #include <atomic>
+#include <mutex>
 
 #define CALS_MAX_MODES 8
 #define CALS_RMAX 64          // rank limit per model; leading dimension of the Gramian stores
@@ -16,13 +17,23 @@ namespace calship {
 
 // hipFuncSetAttribute applies to the current device only: one flag per device for every kernel
 // instantiation that raises its dynamic LDS limit (a process may drive several GPUs, one engine each).
+// ensure(set): runs `set` (the hipFuncSetAttribute call) once per device, under a lock, and records the
+// device as done only AFTER it succeeded -- a second host thread driving another engine on the same
+// device either sees the bit (attribute applied) or waits for the lock; a failure is retried next time.
 struct AttrOnce {
   std::atomic<unsigned long long> done{0};
-  bool need() {
+  std::mutex mu;
+  template <typename F>
+  hipError_t ensure(F &&set) {
     int d = 0;
     (void)hipGetDevice(&d);
     const unsigned long long bit = 1ull << (d & 63);
-    return (done.fetch_or(bit) & bit) == 0;
+    if (done.load(std::memory_order_acquire) & bit) return hipSuccess;
+    std::lock_guard<std::mutex> g(mu);
+    if (done.load(std::memory_order_relaxed) & bit) return hipSuccess;
+    const hipError_t e = set();
+    if (e == hipSuccess) done.fetch_or(bit, std::memory_order_release);
+    return e;
   }
 };
 
@@ -32,7 +43,7 @@ struct AttrOnce {
 enum { CALS_F64 = 0, CALS_F32 = 1 };  // storage type of X, the multi-factors and the partials
 
 struct MttkrpArgs {
-  // element type = dtype (double | float); v1/v2 kernels are fp64 only
+  // element type = dtype (double | float)
   const void *Xp;    // permuted, zero-padded tensor copy for this mode: [Mp][Ap][S], m fastest
   const void *P;     // factor of the inner ("a") mode, A x R, ld = ldP
   const void *Q;     // factor (or Khatri-Rao of the factors) of the streamed modes, S x R, ld = ldQ
@@ -43,10 +54,7 @@ struct MttkrpArgs {
   int R;             // active columns
   int NB, T;         // column blocks, team size (workgroups per column block)
   int ldPart;        // rows of one partial tile (= m_blocks * 16 * MT)
-  int grid;          // NB * T (v1) / NB * m_blocks * T (v2)
-  int m_blocks;      // v2 only: workgroup rows over M ...
-  int k_big;         // ... the first k_big of them have MT tiles, the rest MT - 1
-  int loop_mblocks;  // v2: 1 = each workgroup walks all M blocks (grid = NB * T)
+  int grid;          // NB * T
   int dbg_no_units;  // timing diagnostics only: skip the unit loop (prologue + epilogue cost)
   int dbg_no_stagger;  // v3: 1 = all waves take the barrier mid-slab (A/B test of the stagger)
   int dbg_no_barrier;  // timing diagnostics only (v3): drop the per-stage barrier (results garbage)
@@ -57,11 +65,7 @@ struct MttkrpArgs {
 
 // smallest supported tile count >= mt (0 if mt > max): instantiated MT values
 int mttkrp_pick_mt(int m_tiles);
-size_t mttkrp_lds_bytes(int MT);
-hipError_t mttkrp_launch(int MT, int m_blocks, const MttkrpArgs &a, hipStream_t st);
-// v2 tiling (mttkrp_kernel_v2.hip): two 4-wave workgroups per CU, MT <= 10
-hipError_t mttkrp2_launch(int MT, const MttkrpArgs &a, hipStream_t st);
-// v3 schedule (mttkrp_kernel_v3.hip): v1's tiling, 3-buffer ring, mid-stage barrier
+// mttkrp_kernel_v3.hip: 8-wave tiling, 3-buffer LDS ring, mid-stage barrier
 hipError_t mttkrp3_launch(int MT, int m_blocks, const MttkrpArgs &a, hipStream_t st);
 
 // ---------------------------------------------------------------------------------------------

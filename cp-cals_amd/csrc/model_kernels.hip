@@ -1085,18 +1085,18 @@ hipError_t update_launch(const UpdateArgs &a_in, int rmax_needed, hipStream_t st
   if (big > dyn) dyn = big;  // the two uses of the dynamic region never coexist in one workgroup
   static AttrOnce once_f64, once_f32;  // the limit is raised to the whole budget, once per device
   if (a.dtype == CALS_F32) {
-    if (once_f32.need()) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&update_kernel<float>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)budget);
-      if (e != hipSuccess) return e;
-    }
+    const hipError_t e = once_f32.ensure([&] {
+      return hipFuncSetAttribute(reinterpret_cast<const void *>(&update_kernel<float>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)budget);
+    });
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(update_kernel<float>, dim3(a.n_slots), dim3(UPD_THREADS), dyn, st, a);
   } else {
-    if (once_f64.need()) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&update_kernel<double>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)budget);
-      if (e != hipSuccess) return e;
-    }
+    const hipError_t e = once_f64.ensure([&] {
+      return hipFuncSetAttribute(reinterpret_cast<const void *>(&update_kernel<double>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)budget);
+    });
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(update_kernel<double>, dim3(a.n_slots), dim3(UPD_THREADS), dyn, st, a);
   }
   return hipGetLastError();
@@ -1400,14 +1400,14 @@ hipError_t ls_ec_decide_launch(const LsArgs &a, hipStream_t st) {
   if (a.n_slots <= 0) return hipSuccess;
   const size_t dyn = (size_t)2 * CALS_RMAX * CALS_RMAX * sizeof(double);
   static AttrOnce once;
-  if (once.need()) {
-    hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void *>(&ls_ec_decide_kernel<float>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
-    hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void *>(&ls_ec_decide_kernel<double>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+  const hipError_t ea = once.ensure([&] {
+    const hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void *>(&ls_ec_decide_kernel<float>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
     if (e1 != hipSuccess) return e1;
-    if (e2 != hipSuccess) return e2;
-  }
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(&ls_ec_decide_kernel<double>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+  });
+  if (ea != hipSuccess) return ea;
   if (a.dtype == CALS_F32)
     hipLaunchKernelGGL(ls_ec_decide_kernel<float>, dim3(a.n_slots), dim3(256), dyn, st, a);
   else

@@ -4,11 +4,11 @@
 //
 // = mttkrp::mttkrp of the reference (src/utils/mttkrp.cpp:562-614) with the Khatri-Rao product
 // (:78-216) never materialised: the B operand of every v_mfma_{f64,f32}_16x16x4 is formed in
-// registers as P[a,c]*Q[s,c].  Data layout and work decomposition: DESIGN.md section 2/3.1 and the
-// header of mttkrp_kernel.hip (v1).  Same wave tile as v1 (8 waves x (MT m-tiles x 16 columns)),
-// but the stage-boundary bubble measured on v1 (tools/clock_probe.py: the pipe idled ~1800 of every
-// 21 300 cycles because all 8 waves left the end-of-stage barrier together and refilled their
-// operand pipelines at the same time) is removed:
+// registers as P[a,c]*Q[s,c].  Data layout and work decomposition: DESIGN.md section 2/3.1.
+// Wave tile: 8 waves x (MT m-tiles x 16 columns).  The stage-boundary bubble of a plain
+// double-buffered schedule (round 1's first kernel idled ~1800 of every 21 300 cycles because all 8
+// waves left the end-of-stage barrier together and refilled their operand pipelines at the same
+// time) is removed:
 //   * one slab per stage, a ring of THREE LDS buffers;
 //   * the only barrier of a stage sits in the MIDDLE of its MFMA stream (waves 0-3) or at its
 //     start (waves 4-7: stagger, MI355X_MICROARCH "two waves per SIMD" item 9): there "slab i+1 has
@@ -320,15 +320,23 @@ __global__ void __launch_bounds__(512, 2) mttkrp3_kernel(const MttkrpArgs a) {
   }
 }
 
+// ---- host side ----
+static const int kMtSet[] = {1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16, 19, 20};
+
+int mttkrp_pick_mt(int m_tiles) {
+  for (int v : kMtSet)
+    if (v >= m_tiles) return v;
+  return 0;
+}
+
 template <int MT, typename T>
 static hipError_t launch3_mt(int m_blocks, const MttkrpArgs &a, hipStream_t st) {
   static AttrOnce attr_once;
-  if (attr_once.need()) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&mttkrp3_kernel<MT, T>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       Mt3Cfg<MT, T>::LDS_BYTES);
-    if (e != hipSuccess) return e;
-  }
+  hipError_t e = attr_once.ensure([] {
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(&mttkrp3_kernel<MT, T>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, Mt3Cfg<MT, T>::LDS_BYTES);
+  });
+  if (e != hipSuccess) return e;
   dim3 grid(a.grid, m_blocks, 1), block(512, 1, 1);
   constexpr int lds_bytes = Mt3Cfg<MT, T>::LDS_BYTES;
   hipLaunchKernelGGL((mttkrp3_kernel<MT, T>), grid, block, lds_bytes, st, a);
@@ -355,6 +363,37 @@ hipError_t mttkrp3_launch(int MT, int m_blocks, const MttkrpArgs &a, hipStream_t
 #undef CASE
   }
   return hipErrorInvalidValue;
+}
+
+// Khatri-Rao of the streamed modes (N > 3): Q[s, c] = prod_k F_k[i_k(s), c], first mode fastest.
+// Restates khatri_rao_rec's ordering (src/utils/mttkrp.cpp:147-176).  Small next to the MTTKRP.
+template <typename E>
+__global__ void krp_kernel(const KrpArgs a) {
+  const long long total = a.S * a.R;
+  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total;
+       e += (long long)gridDim.x * blockDim.x) {
+    const long long c = e / a.S;
+    long long s = e - c * a.S;
+    double v = 1.0;
+    for (int k = 0; k < a.n; ++k) {
+      const long long i = s % a.dims[k];
+      s /= a.dims[k];
+      v *= (double)static_cast<const E *>(a.F[k])[i + a.ld[k] * c];
+    }
+    static_cast<E *>(a.Q)[e] = (E)v;
+  }
+}
+
+hipError_t krp_launch(const KrpArgs &a, hipStream_t st) {
+  const long long total = a.S * a.R;
+  if (total <= 0) return hipSuccess;
+  long long blocks = (total + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  if (a.dtype == CALS_F32)
+    hipLaunchKernelGGL(krp_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL(krp_kernel<double>, dim3((unsigned)blocks), dim3(256), 0, st, a);
+  return hipGetLastError();
 }
 
 }  // namespace calship

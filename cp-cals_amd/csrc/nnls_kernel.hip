@@ -350,10 +350,9 @@ hipError_t nnls_launch(const NnlsArgs &a_in, hipStream_t st) {
   const int di = (a.dtype == CALS_F32) ? 1 : 0;
   const void *fn = di ? reinterpret_cast<const void *>(&nnls_kernel<float>)
                       : reinterpret_cast<const void *>(&nnls_kernel<double>);
-  if (once[di].need()) {
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)budget);
-    if (e != hipSuccess) return e;
-  }
+  const hipError_t ea = once[di].ensure(
+      [&] { return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)budget); });
+  if (ea != hipSuccess) return ea;
   const dim3 grid((unsigned)(a.n_slots * chunks)), block(64 * waves);
   if (di)
     hipLaunchKernelGGL(nnls_kernel<float>, grid, block, dyn, st, a);

@@ -539,11 +539,11 @@ template <int MT, typename T>
 static hipError_t ttm_launch_mt(const TtmArgs &a, hipStream_t st) {
   static AttrOnce attr_once;
   constexpr int lds_bytes = TtmCfg<MT, T>::LDS_BYTES;
-  if (attr_once.need()) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&ttm_kernel<MT, T>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-    if (e != hipSuccess) return e;
-  }
+  const hipError_t e = attr_once.ensure([] {
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(&ttm_kernel<MT, T>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+  });
+  if (e != hipSuccess) return e;
   dim3 grid(a.grid, 1, 1), block(512, 1, 1);
   hipLaunchKernelGGL((ttm_kernel<MT, T>), grid, block, lds_bytes, st, a);
   return hipGetLastError();

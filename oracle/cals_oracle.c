@@ -1306,6 +1306,40 @@ int or_lsap_bruteforce(int n, const double *cost, int maximize, int64_t *col_of_
   return 0;
 }
 
+/* jk_permutation_adjustment for ONE replica, utils.cpp:54-101 -- restated with the reference's
+ * orientation: it builds M(a, b) = <Bov_a, Bm_b> + <Cov_a, Cm_b> (a = overall column, b = replica
+ * column) COLUMN-major (utils.cpp:69-74) and passes the buffer to
+ * solve_rectangular_linear_sum_assignment (utils.cpp:79), which reads ROW-major
+ * (rectangular_lsap.cpp:93).  The problem actually solved has row b = replica column, column a =
+ * overall column, i.e. the cost matrix Mt(b, a) = M(a, b); solved[b] = the overall column matched to
+ * replica column b.  or_lsap_bruteforce takes a column-major cost with rows first, so Mt is stored as
+ * Mt[b + r * a].  Then new(:, cur) = old(:, solved[cur]) in every mode (utils.cpp:81-97). */
+int or_jk_permutation_adjust(int n_modes, const int64_t *modes, int64_t r, const double *const *overall,
+                             double *const *replica) {
+  if (r < 1 || r > 9 || n_modes < 3) return -1;
+  double *M = (double *)xmalloc(sizeof(double) * (size_t)(r * r));
+  for (int64_t b = 0; b < r; b++)
+    for (int64_t a = 0; a < r; a++) {
+      double s = 0.0, t = 0.0;
+      for (int64_t q = 0; q < modes[1]; q++) s += overall[1][q + modes[1] * a] * replica[1][q + modes[1] * b];
+      for (int64_t q = 0; q < modes[2]; q++) t += overall[2][q + modes[2] * a] * replica[2][q + modes[2] * b];
+      M[b + r * a] = s + t;
+    }
+  int64_t solved[9];
+  if (or_lsap_bruteforce((int)r, M, 1, solved)) { free(M); return -3; }
+  free(M);
+  for (int n = 0; n < n_modes; n++) {
+    const size_t bytes = sizeof(double) * (size_t)(modes[n] * r);
+    double *copy = (double *)xmalloc(bytes);
+    memcpy(copy, replica[n], bytes);
+    for (int64_t cur = 0; cur < r; cur++)
+      if (solved[cur] != cur)
+        memcpy(replica[n] + modes[n] * cur, copy + modes[n] * solved[cur], sizeof(double) * (size_t)modes[n]);
+    free(copy);
+  }
+  return 0;
+}
+
 int or_jk_cp_cals(const double *X, int n_modes, const int64_t *modes, const or_model *kt_vector,
                   int64_t n_models, const or_params *params, or_model *results, or_report *rep) {
   const int64_t I0 = modes[0];
@@ -1345,26 +1379,7 @@ int or_jk_cp_cals(const double *X, int n_modes, const int64_t *modes, const or_m
     /* jk_permutation_adjustment, utils.cpp:54-101 */
     for (int64_t i = 0; i < I0; i++) {
       or_model *m = &results[k * I0 + i];
-      double *M = (double *)xmalloc(sizeof(double) * (size_t)(r * r));
-      for (int64_t b = 0; b < r; b++)
-        for (int64_t a = 0; a < r; a++) {
-          double s = 0.0, t = 0.0;
-          for (int64_t q = 0; q < modes[1]; q++) s += over[k].fac[1][q + modes[1] * a] * m->factors[1][q + modes[1] * b];
-          for (int64_t q = 0; q < modes[2]; q++) t += over[k].fac[2][q + modes[2] * a] * m->factors[2][q + modes[2] * b];
-          M[a + r * b] = s + t;
-        }
-      int64_t solved[9];
-      if (or_lsap_bruteforce((int)r, M, 1, solved)) { free(M); return -3; }
-      free(M);
-      for (int n = 0; n < n_modes; n++) {
-        const size_t bytes = sizeof(double) * (size_t)(modes[n] * r);
-        double *copy = (double *)xmalloc(bytes);
-        memcpy(copy, m->factors[n], bytes);
-        for (int64_t cur = 0; cur < r; cur++)
-          if (solved[cur] != cur)
-            memcpy(m->factors[n] + modes[n] * cur, copy + modes[n] * solved[cur], sizeof(double) * (size_t)modes[n]);
-        free(copy);
-      }
+      if (or_jk_permutation_adjust(n_modes, modes, r, (const double *const *)over[k].fac, m->factors)) return -3;
     }
     kt_free(&over[k]);
   }

@@ -131,8 +131,14 @@ int or_cp_cals(const double *X, int n_modes, const int64_t *modes, or_model *mod
  * model k at results[k * modes[0] + i]) after re-normalisation and column matching
  * (utils::jk_permutation_adjustment, src/utils/utils.cpp:54-101).  The assignment problem, which
  * the reference hands to SciPy's rectangular_lsap (extern/), is solved here by exhaustive search
- * (rank <= 9): an independent check of the product's Hungarian solver. */
+ * (rank <= 9): an independent check of the product's solver.  The reference's own rectangular_lsap.cpp
+ * is self-contained, so oracle/Makefile also builds it from where it lies (oracle/_ref/) and the tests
+ * pin both against it. */
 int or_lsap_bruteforce(int n, const double *cost_colmajor, int maximize, int64_t *col_of_row);
+/* utils::jk_permutation_adjustment for one replica (factors in place), with the reference's
+ * orientation of the assignment problem (see the definition). */
+int or_jk_permutation_adjust(int n_modes, const int64_t *modes, int64_t r, const double *const *overall,
+                             double *const *replica);
 int or_jk_cp_cals(const double *X, int n_modes, const int64_t *modes, const or_model *kt_vector,
                   int64_t n_models, const or_params *params, or_model *results, or_report *rep);
 
