@@ -3,18 +3,24 @@
 
   python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
 
-A step = one ALS sweep (every mode: fused MTTKRP + batched update; error; line search) of all
-models in flight on a GPU.  Workload (BASELINE.json config 3, the one north_star's target is quoted
-on): 300x300x300 fp64 tensor, 256 concurrent models of rank 1 + (k mod 20) per GPU (R = 2656
-columns), line search on (NO_ERROR_CHECKING, interval 5, step cbrt(iter)); synthetic inputs from
+A step = one ALS sweep (every mode: MTTKRP + batched update; error; line search) of all models in
+flight on a GPU.  Workload (BASELINE.json config 3, the one north_star's target is quoted on):
+300x300x300 fp64 tensor, 256 concurrent models of rank 1 + (k mod 20) per GPU (R = 2656 columns), line
+search on (NO_ERROR_CHECKING, interval 5, step cbrt(iter)); synthetic inputs from
 cp-cals_amd/inputs.py.  X, factors and all model state are resident in HBM before the timed region.
 N > 1: weak scaling, every rank owns its own 256-model shard (model m -> GPU m mod N), X replicated,
 no data-path collective; value = sweeps completed by all ranks / max-over-ranks time.
-Rank 0 prints ONE JSON line.
+--workload c5 = BASELINE config 5: 2048 jackknife models IN TOTAL (jk = (mode 0, fiber m mod 300)),
+model m -> GPU m mod N, strong scaling (a step = one sweep of the whole job).
+Rank 0 prints ONE JSON line: the contract fields, `roofline`, `cpu_baseline`, and beside them
+`steady_state` (>= 200 further sweeps), `run_loop` (the cals_hip_step loop users run: status
+read-back + eviction decision every sweep) and `dist` (backend, world size seen by the process
+group, per-rank ms/step).
 """
 import argparse
 import json
 import os
+import platform
 import sys
 import time
 
@@ -28,58 +34,93 @@ WORKLOADS = {
     "c1": ([20, 20, 20], 4, 0),        # BASELINE config 1 (plumbing)
     "c4": ([299, 301, 41], 512, 0),    # BASELINE config 4: eemdata-shaped, fp32 storage + fp32 MFMA
     "c4f64": ([299, 301, 41], 512, 0),  # config 4's shape and model count, in fp64
-    # BASELINE config 5: 2048 models IN TOTAL sharded round-robin over the N GPUs (strong scaling:
-    # a step = one sweep of all 2048 models; value = steps / max time).  N = 1 gives the denominator of
-    # north_star's ">= 6x at 8 GPUs".
+    # BASELINE config 5: 2048 jackknife models IN TOTAL sharded round-robin over the N GPUs (strong
+    # scaling: a step = one sweep of all 2048 models; value = steps / max time).  N = 1 gives the
+    # denominator of north_star's ">= 6x at 8 GPUs".
     "c5": ([300, 300, 300], 2048, 1),
 }
 STRONG = {"c5"}
+JACKKNIFE = {"c5"}     # every model carries jk = (mode 0, fiber m mod I0)  
 WORKLOAD_DTYPE = {"c4": "f32"}
 PEAK_FP32_MFMA_TFLOPS = 157.3  # dense FP32 matrix peak (v_mfma_f32_16x16x4_f32: 256 flop/cycle/CU x4 SIMD)
 PEAK_FP64_MFMA_TFLOPS = 78.6  # MI355X dense FP64 matrix peak (datasheet; 256 CU x 4 SIMD x 2.4 GHz
 #                               x 2048 flop / 64 cycles).  tools/mfma_f64_peak measures 77.7 on the box.
 
 
-def local_ranks(k_models):
-    return [1 + (k % 20) for k in range(k_models)]
+def cpu_model_name():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return platform.processor() or "unknown"
 
 
-def cpu_baseline(modes, ranks, X, base, ls, threads, sweeps):
-    """The oracle (CPU restatement of the reference algorithm, explicit KRP + GEMM / two-step) with
-    the image's MKL runtime for the big GEMMs, on a bounded sample of the same workload."""
+def cpu_baseline(modes, ranks, X, base, jk, ls, threads_all, protocol):
+    """The oracle (CPU restatement of the reference algorithm) with the image's MKL runtime for the big
+    GEMMs, on the GPU box's host cores -- SURVEY.md section 8(d), protocol of the reference's
+    include/experiments/bench_mttkrp_cals.h:49-84: MTTKRP variants {MTTKRP, TWOSTEP0, TWOSTEP1} each
+    timed after one warm-up sweep, best of `reps` repetitions of `sweeps` forced sweeps, best variant
+    reported, for threads in {all of the cgroup's share, 1}.  protocol "bounded" (default: the bench
+    has to finish within minutes) = 1 repetition of 3 sweeps at all threads, the best variant only
+    (1 sweep) at 1 thread; protocol "full" = 3 x 10 sweeps at all threads, 1 x 2 sweeps at 1 thread."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle as O
-    have_mkl = O.use_mkl(threads)
-    O.set_threads(threads)
-    best = None
-    for name, method in (("AUTO(no LUT)", O.AUTO), ("MTTKRP", O.MTTKRP)):
-        models = [O.Model([f.copy() for f in fs], lam.copy()) for fs, lam in base]
+    plan = {"bounded": {"all": (1, 3), "one": (1, 1)}, "full": {"all": (3, 10), "one": (1, 2)}}[protocol]
+    have_mkl = O.use_mkl(threads_all)
+    variants = (("MTTKRP", O.MTTKRP), ("TWOSTEP0", O.TWOSTEP0), ("TWOSTEP1", O.TWOSTEP1))
+
+    def run(method, threads, sweeps):
+        models = [O.Model([f.copy() for f in fs], lam.copy(), jk=None if jk is None else jk[k])
+                  for k, (fs, lam) in enumerate(base)]
         p = O.default_params(max_iterations=sweeps, force_max_iter=1, buffer_size=sum(ranks),
-                             mttkrp_method=method, line_search=ls, line_search_interval=5,
-                             threads=threads)
+                             mttkrp_method=method, line_search=ls, line_search_interval=5, threads=threads)
         rep = O.cp_cals(X, modes, models, p)
-        rate = rep.iter / rep.loop_time
-        if best is None or rate > best[0]:
-            best = (rate, name)
+        return rep.iter / rep.loop_time
+
+    def measure(threads, reps, sweeps, only=None):
+        O.use_mkl(threads)
+        O.set_threads(threads)
+        table = {}
+        for name, method in variants:
+            if only is not None and name != only:
+                continue
+            run(method, threads, 1)  # warm-up sweep (thread pools, page faults of the KRP workspace)
+            table[name] = max(run(method, threads, sweeps) for _ in range(reps))
+        return table
+
+    t_all = measure(threads_all, *plan["all"])
+    best = max(t_all, key=t_all.get)
+    t_one = measure(1, *plan["one"], only=None if protocol == "full" else best)
+    best_one = max(t_one, key=t_one.get)
     O.use_own_gemm()
     O.set_threads(1)
     return {
-        "value": round(best[0], 4), "unit": "ALS it/s", "cores": threads, "kind": "port",
-        "sample": "%d forced sweeps of the same workload per MTTKRP variant {AUTO(no LUT), MTTKRP}, "
-                  "best variant (%s) reported; GEMMs by %s, %d threads" % (
-                      sweeps, best[1], "MKL (libmkl_rt, image runtime)" if have_mkl else "the oracle's own loops",
-                      threads),
+        "value": round(t_all[best], 4), "unit": "ALS it/s", "cores": threads_all, "kind": "port",
+        "variant": best, "per_variant": {k: round(v, 4) for k, v in t_all.items()},
+        "single_thread": {"value": round(t_one[best_one], 4), "cores": 1, "variant": best_one,
+                          "per_variant": {k: round(v, 4) for k, v in t_one.items()}},
+        "cpu": cpu_model_name(), "protocol": protocol,
+        "sample": "same workload (X, models, line search); per MTTKRP variant 1 warm-up sweep, then best of "
+                  "%d x %d forced sweeps at %d threads; at 1 thread %s, %d x %d sweeps; GEMMs by %s" % (
+                      plan["all"][0], plan["all"][1], threads_all,
+                      "all variants" if protocol == "full" else "the best variant only",
+                      plan["one"][0], plan["one"][1],
+                      "MKL (libmkl_rt, image runtime)" if have_mkl else "the oracle's own loops"),
     }
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)   # SURVEY.md section 8(d): 50 sweeps
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--steady-steps", type=int, default=200,
+                    help="further sweeps timed after the K steps for the `steady_state` field (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=0)
-    ap.add_argument("--cpu-sweeps", type=int, default=2)
+    ap.add_argument("--cpu-protocol", default="bounded", choices=["bounded", "full"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL) for real multi-GPU runs; gloo only to rehearse the N>1 path")
@@ -87,7 +128,7 @@ def main():
                     help="rehearsal on a 1-GPU box: every rank uses cuda:0 (use with --dist-backend gloo)")
     args = ap.parse_args()
 
-    import numpy as np
+    import numpy as np  # noqa: F401
     import torch
     import torch.distributed as dist
     import cp_cals_amd as cc
@@ -109,33 +150,38 @@ def main():
         raise SystemExit("rank %d: LOCAL_RANK %d but only %d GPU(s) visible" % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    pg_world = 1
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = args.dist_backend
-        if backend == "nccl":
-            try:
-                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-            except Exception as exc:  # control plane only (barrier + max of a scalar): gloo does it too
-                print("rank %d: RCCL process group failed (%s); using gloo" % (rank, exc), file=sys.stderr)
-                backend = "gloo"
-        if backend == "gloo":
+        # the requested backend or nothing: a record that says "nccl" must mean RCCL saw `world` ranks
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
-        args.dist_backend = backend
+        pg_world = dist.get_world_size()
+        if pg_world != world or dist.get_backend() != args.dist_backend:
+            raise SystemExit("process group: backend %s, %d ranks; wanted %s, %d" % (
+                dist.get_backend(), pg_world, args.dist_backend, world))
     red_dev = dev if (world == 1 or args.dist_backend == "nccl") else torch.device("cpu")
 
     modes, k_models, ls = WORKLOADS[args.workload]
     strong = args.workload in STRONG
     if strong:
         total_models = k_models
-        mine = list(range(rank, total_models, world))   # model m -> GPU m mod N
-        k_models = len(mine)
-        ranks = [1 + (m % 20) for m in mine]
+        mine = sharding.shard_round_robin(total_models, world, rank)   # model m -> GPU m mod N
     else:
         total_models = k_models * world
-        ranks = local_ranks(k_models)       # this rank's shard: models m = rank + world*k
+        mine = [rank + world * k for k in range(k_models)]   # this rank's shard: models m = rank + world*k
+    k_models = len(mine)
+    ranks = [1 + (m % 20) for m in mine] if strong else [1 + (k % 20) for k in range(k_models)]
     R = sum(ranks)
     X = inputs.tensor(modes, seed=0)        # replicated: every rank generates the same X
     base = inputs.model_factors(modes, ranks, seed=1 + rank)
+    jk = None
+    if args.workload in JACKKNIFE:
+        jk = [(0, m % modes[0]) for m in mine]
+        for (fs, _), (jm, jf) in zip(base, jk):
+            fs[jm][jf, :] *= 0.0            # Ktensor::fill zeroes the jk fiber (src/ktensor.cpp:21-30)
 
     dtype = WORKLOAD_DTYPE.get(args.workload, "f64")
     peak = PEAK_FP32_MFMA_TFLOPS if dtype == "f32" else PEAK_FP64_MFMA_TFLOPS
@@ -143,7 +189,8 @@ def main():
     eng.set_tensor(X)
     eng.set_params(cc.default_params(max_iterations=10 ** 9, force_max_iter=1, line_search=ls,
                                      line_search_interval=5, line_search_step=0.0))
-    models = [cc.Model([f.copy() for f in fs], lam.copy()) for fs, lam in base]
+    models = [cc.Model([f.copy() for f in fs], lam.copy(), jk=None if jk is None else jk[k])
+              for k, (fs, lam) in enumerate(base)]
     for m in models:
         eng.enqueue(m)
     assert eng.admit() == k_models and eng.active_cols == R
@@ -161,12 +208,43 @@ def main():
     sharding.barrier()
     elapsed = time.perf_counter() - t0
 
-    value, t_max = sharding.aggregate_rate(args.steps, elapsed, device=red_dev)
     if strong:
-        value = args.steps / t_max          # one step advances the WHOLE job by one sweep
+        value, t_max = sharding.strong_rate(args.steps, elapsed, device=red_dev)
+    else:
+        value, t_max = sharding.aggregate_rate(args.steps, elapsed, device=red_dev)
+    per_rank_ms = [round(t / args.steps * 1e3, 4) for t in sharding.gather_over_ranks(elapsed, device=red_dev)]
     ks = eng.kernel_stats()
     plan = eng.tree
     eng.set_profiling(False)
+
+    # ---- beside the contract: the long-run rate and the loop users run (not part of `value`) ----
+    steady = run_loop = None
+    if args.steady_steps > 0:
+        sharding.barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        eng.sweep(args.steady_steps)
+        torch.cuda.synchronize()
+        sharding.barrier()
+        dt = time.perf_counter() - t1
+        sv, st_max = (sharding.strong_rate if strong else sharding.aggregate_rate)(args.steady_steps, dt, device=red_dev)
+        steady = {"steps": args.steady_steps, "value": round(sv, 3), "unit": "ALS it/s",
+                  "ms_per_step": round(st_max / args.steady_steps * 1e3, 4),
+                  "after_sweeps": args.warmup + args.steps,
+                  "note": "back-to-back sweeps right after the K timed steps, same engine state"}
+        n_loop = min(args.steady_steps, 100)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        for _ in range(n_loop):
+            eng.step()                      # admit (nothing queued) + sweep + status read-back + eviction rule
+        eng.synchronize()
+        dt2 = time.perf_counter() - t2
+        assert eng.models_in_flight == k_models
+        rv, rt_max = (sharding.strong_rate if strong else sharding.aggregate_rate)(n_loop, dt2, device=red_dev)
+        run_loop = {"steps": n_loop, "value": round(rv, 3), "unit": "ALS it/s",
+                    "ms_per_step": round(rt_max / n_loop * 1e3, 4),
+                    "note": "cals_hip_step loop = one iteration of cals_hip_run (src/cals.cpp:174-382): per-sweep "
+                            "status read-back and eviction decision included (force_max_iter: nothing leaves)"}
 
     out = None
     if rank == 0:
@@ -203,15 +281,17 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(t_max / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": dtype,
             "data": "synthetic",
-            "config": {"workload": ("%s %s dense tensor, %d concurrent CP models per GPU, ranks 1..20 "
+            "config": {"workload": ("%s %s dense tensor, %d concurrent %sCP models per GPU, ranks 1..20 "
                                     "(R=%d columns), line search %s; " % (
                                         "x".join(map(str, modes)), "fp32" if dtype == "f32" else "fp64",
-                                        k_models, R, "on" if ls else "off")) + (
+                                        k_models, "jackknife (jk = mode 0, fiber m mod %d) " % modes[0] if jk else "",
+                                        R, "on" if ls else "off")) + (
                                     "one step = one ALS sweep of ALL %d models (sharded over %d GPU(s)); "
                                     "value = steps / max time" % (total_models, world) if strong else
                                     "one step = one ALS sweep of a GPU's model shard; value = sweeps by all "
                                     "%d GPU(s) / max time" % world),
                        "name": args.workload, "models_per_gpu": k_models, "total_models": total_models,
+                       "jackknife": bool(jk),
                        "sharding": "model m -> GPU m mod N, X replicated, no data-path collective"},
             "roofline": {"bound": "mfma", "kernel": "%s, v_mfma_%s" % (
                              dom, "f32_16x16x4_f32" if dtype == "f32" else "f64_16x16x4_f64"),
@@ -226,13 +306,20 @@ def main():
                          "mfma_kernels": kern, "contract_kernel": contract,
                          "rest_ms_per_step": round(
                              t_max / args.steps * 1e3 - (ks.mttkrp_ms + ks.ttm_ms + ks.contract_ms) / args.steps, 4)},
+            "steady_state": steady,
+            "run_loop": run_loop,
+            "dist": {"backend": args.dist_backend if world > 1 else None, "world_size": pg_world,
+                     "ms_per_step_per_rank": per_rank_ms},
         }
     eng.close()
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and not strong:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload != "c5":
         threads = args.cpu_threads or min(len(os.sched_getaffinity(0)), 16)
-        out["cpu_baseline"] = cpu_baseline(modes, ranks, X, base, ls, threads, args.cpu_sweeps)
+        out["cpu_baseline"] = cpu_baseline(modes, ranks, X, base, jk, ls, threads, args.cpu_protocol)
     elif rank == 0:
         out["cpu_baseline"] = None
+        if world == 1 and args.workload == "c5" and not args.no_cpu_baseline:
+            out["cpu_baseline_note"] = ("not timed for c5: one oracle sweep of 2048 models is ~8x config 3's "
+                                        "(~12 s at 16 threads); the c3 line carries the CPU baseline")
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -1,5 +1,6 @@
 // CLI demo on the C++ layer, with the options of the reference's src/examples/driver.cpp
-// (-n threads [ignored: no host BLAS], -c MIN:MAX:COPIES, -t I-J-K) plus -d DEVICE and -p f64|f32:
+// (-n threads [ignored: no host BLAS], -c MIN:MAX:COPIES, -t I-J-K) plus -d DEVICE, -p f64|f32 and
+// -f FILE (the target tensor from a text file, Tensor(file_name), src/tensor.cpp:35-65):
 // fits COPIES models of every rank MIN..MAX to a random tensor with concurrent ALS on the GPU and,
 // for comparison, one model at a time (cp_als, same engine), and prints both times.
 #include <iostream>
@@ -8,6 +9,7 @@
 #include <vector>
 
 #include "../cals/cals.h"
+#include "crash_trace.h"
 
 using std::cerr;
 using std::cout;
@@ -24,6 +26,8 @@ static void split(const std::string &s, std::vector<dim_t> &out, char sep) {
 }
 
 int main(int argc, char **argv) {
+  crash_trace::install();  // a crash, also one at process exit, leaves its own backtrace on stderr
+  std::string tensor_file;
   std::vector<dim_t> modes = {210, 210, 210};
   int min_c = 1, max_c = 10, copies = 5, device = 0;
   std::vector<int> devices;
@@ -31,7 +35,7 @@ int main(int argc, char **argv) {
   for (int i = 1; i < argc; ++i) {
     const std::string arg = argv[i];
     if ((arg == "-h") || (arg == "--help")) {
-      cout << "Usage: " << argv[0] << " [-n THREADS] [-c MIN:MAX:COPIES] [-t I-J-K] [-d DEVICE] [-p f64|f32]" << endl;
+      cout << "Usage: " << argv[0] << " [-n THREADS] [-c MIN:MAX:COPIES] [-t I-J-K] [-f TENSOR_FILE] [-d DEVICE] [-p f64|f32]" << endl;
       return 0;
     } else if ((arg == "-n" || arg == "--nthreads") && i + 1 < argc) {
       ++i;  // host BLAS threads: meaningless on the device path
@@ -53,6 +57,8 @@ int main(int argc, char **argv) {
         return 1;
       }
       modes = v;
+    } else if ((arg == "-f" || arg == "--file") && i + 1 < argc) {
+      tensor_file = argv[++i];
     } else if ((arg == "-d" || arg == "--device") && i + 1 < argc) {
       device = (int)std::strtol(argv[++i], nullptr, 10);
     } else if (arg == "--devices" && i + 1 < argc) {  // e.g. 0,1,2,3: one engine per listed GPU, shared queue
@@ -71,8 +77,20 @@ int main(int argc, char **argv) {
       return 1;
     }
   }
-  cals::Tensor X(modes);
-  X.randomize();
+  cals::Tensor X;
+  try {
+    if (!tensor_file.empty()) {
+      X = cals::Tensor(tensor_file);
+      modes = X.get_modes();
+      cout << "Tensor read from " << tensor_file << ": " << cals::utils::mode_string(modes) << endl;
+    } else {
+      X = cals::Tensor(modes);
+      X.randomize();
+    }
+  } catch (const std::exception &e) {
+    cerr << e.what() << endl;
+    return 2;
+  }
   std::vector<dim_t> components;
   for (int c = min_c; c <= max_c; c++)
     for (int k = 0; k < copies; k++) components.push_back((dim_t)c);

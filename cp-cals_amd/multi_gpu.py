@@ -20,16 +20,22 @@ import torch.distributed as dist
 class WorkQueue:
     """Indices 0 .. n_items-1 handed out in claim order through an atomic counter on a TCPStore."""
 
-    def __init__(self, n_items, name="cals_work_queue", store=None):
+    def __init__(self, n_items, name="cals_work_queue", store=None, port=None):
+        """store: any torch.distributed store with add(); default = the process group's own rendezvous
+        store behind a prefix (no extra port).  port: only if that store is not reachable -- a TCPStore on
+        MASTER_ADDR:port, chosen by the caller (never guessed from MASTER_PORT)."""
         self.n = int(n_items)
         self.key = name
         self._local = 0  # single-process fall-back
         self.store = store
         if self.store is None and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            host = os.environ.get("MASTER_ADDR", "127.0.0.1")
-            port = int(os.environ.get("MASTER_PORT", "29500")) + 1 + int(os.environ.get("CALS_QUEUE_PORT_OFFSET", "0"))
-            self.store = dist.TCPStore(host, port, dist.get_world_size(), is_master=(dist.get_rank() == 0),
-                                       wait_for_workers=True)
+            if port is None:
+                base = dist.distributed_c10d._get_default_store()
+                self.store = dist.PrefixStore("cals_work_queue/" + name, base)
+            else:
+                host = os.environ.get("MASTER_ADDR", "127.0.0.1")
+                self.store = dist.TCPStore(host, int(port), dist.get_world_size(), is_master=(dist.get_rank() == 0),
+                                           wait_for_workers=True)
 
     def claim(self, count):
         """Claims up to `count` indices; returns a (possibly empty) list."""

@@ -33,6 +33,16 @@ def sum_over_ranks(value, device="cpu"):
     return float(t.item())
 
 
+def gather_over_ranks(value, device="cpu"):
+    """[value of rank 0, value of rank 1, ...] on every rank."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return [float(value)]
+    mine = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    parts = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(parts, mine)
+    return [float(p.item()) for p in parts]
+
+
 def barrier():
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.barrier()
@@ -43,3 +53,10 @@ def aggregate_rate(local_units, local_seconds, device="cpu"):
     total = sum_over_ranks(local_units, device)
     t = max_over_ranks(local_seconds, device)
     return total / t, t
+
+
+def strong_rate(job_steps, local_seconds, device="cpu"):
+    """Strong scaling (BASELINE config 5): the job's models are split over the ranks and one step advances
+    the WHOLE job by one sweep, so the job rate is steps / MAX over ranks of the elapsed time."""
+    t = max_over_ranks(local_seconds, device)
+    return job_steps / t, t

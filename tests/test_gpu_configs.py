@@ -1,0 +1,180 @@
+"""BASELINE.json configs 3 and 5 exercised AS CONFIGURED, through the C ABI (cals_hip_run):
+
+  C3  300^3 fp64, 256 models of rank 1 + (m mod 20) (R = 2656), line search NO_ERROR_CHECKING
+      interval 5 step cbrt(iter), plan M (multi-sweep dimension tree) -- exactly what bench.py times --
+      for 12 forced sweeps against the CPU oracle (reference loop src/cals.cpp:174-382, line search
+      src/utils/line_search.cpp:228-271): factors / lambda <= 1e-8 (north_star's tolerance), identical
+      sweep count, per-model iterations and line-search extrapolate / revert counts; plan 0 (three
+      fused MTTKRPs) gives the same models; the fast error equals the brute-force error.
+  C5  300^3 fp64, 2048 models, model m -> GPU m mod 8, every model a jackknife replica
+      jk = (mode 0, fiber m mod 300) (src/cals.cpp:198-200, 291-296): GPU 0's shard
+      (256 models) against the oracle; then all 2048 models on one engine (the strong-scaling
+      denominator) against the shard engine, jk rows exactly zero, jk error == brute force on
+      ||X without slice i||.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import reconstruct, rel
+
+pytestmark = pytest.mark.gpu
+TOL_RUN = 1e-8  # relative Frobenius, fp64 (BASELINE.json north_star)
+MODES = [300, 300, 300]
+
+
+def _threads():
+    return min(len(os.sched_getaffinity(0)), 16)
+
+
+def _engine(cc, X, base, params, jk=None, tree=None, buffer=None):
+    old = os.environ.get("CALS_HIP_TREE")
+    if tree is not None:
+        os.environ["CALS_HIP_TREE"] = tree
+    try:
+        e = cc.Engine(MODES, sum(f[0].shape[1] for f, _ in base) if buffer is None else buffer)
+    finally:
+        if tree is not None:
+            if old is None:
+                del os.environ["CALS_HIP_TREE"]
+            else:
+                os.environ["CALS_HIP_TREE"] = old
+    e.set_tensor(X)
+    e.set_params(params)
+    gm = [cc.Model([f.copy() for f in fs], lam.copy(), jk=None if jk is None else jk[k])
+          for k, (fs, lam) in enumerate(base)]
+    for m in gm:
+        e.enqueue(m)
+    return e, gm
+
+
+def _compare(gm, om, tol=TOL_RUN):
+    worst = 0.0
+    for g, o in zip(gm, om):
+        assert g.iters == o.iters
+        for fa, fb in zip(g.factors, o.factors):
+            worst = max(worst, rel(fa, fb))
+        worst = max(worst, rel(g.lam, o.lam))
+        assert abs(g.error - o.error) <= 1e-8 * max(1.0, abs(o.error))
+        assert abs(g.fit - o.fit) <= 1e-10
+    assert worst < tol, worst
+    return worst
+
+
+def test_c3_as_benched_vs_oracle(cc, oracle, inputs):
+    iters = 12
+    ranks = inputs.ranks_1_to_20(256)
+    X = inputs.tensor(MODES, 0)
+    base = inputs.model_factors(MODES, ranks, 1)
+    prm = cc.default_params(max_iterations=iters, force_max_iter=1, line_search=1, line_search_interval=5,
+                            line_search_step=0.0)
+    e, gm = _engine(cc, X, base, prm)
+    assert e.tree == 3, "the cost model must pick plan M for config 3 (what bench.py times)"
+    rep = e.run()
+    e.close()
+    assert rep.iter == iters and rep.n_ktensors == 256 and rep.ktensor_comp_sum == 2656
+
+    th = _threads()
+    oracle.use_mkl(th)
+    oracle.set_threads(th)
+    try:
+        om = [oracle.Model([f.copy() for f in fs], lam.copy()) for fs, lam in base]
+        orep = oracle.cp_cals(X, MODES, om, oracle.default_params(
+            max_iterations=iters, force_max_iter=1, buffer_size=sum(ranks), mttkrp_method=oracle.MTTKRP,
+            line_search=1, line_search_interval=5, threads=th))
+    finally:
+        oracle.use_own_gemm()
+        oracle.set_threads(1)
+    assert orep.iter == iters
+    assert (rep.ls_performed, rep.ls_failed) == (orep.ls_performed, orep.ls_failed)
+    assert rep.ls_performed > 0
+    worst = _compare(gm, om)
+    print("C3 as benched: worst rel. diff vs oracle %.2e, ls %d/%d" % (worst, rep.ls_performed, rep.ls_failed))
+
+    # plan 0 (three fused MTTKRPs per sweep) fits the same models: same sums, other association
+    e0, g0 = _engine(cc, X, base, prm, tree="0")
+    assert e0.tree == 0
+    rep0 = e0.run()
+    e0.close()
+    assert (rep0.iter, rep0.ls_performed, rep0.ls_failed) == (rep.iter, rep.ls_performed, rep.ls_failed)
+    _compare(g0, gm)
+
+    # fast error == brute-force error (reference ComputeCorrectError, tests/als/test_als.cpp:125-145)
+    for m in (gm[19], gm[100], gm[255]):
+        slow = np.linalg.norm(X - reconstruct(m.factors, m.lam, MODES))
+        assert abs(m.error - slow) <= 1e-9 * slow
+
+
+def _c5_models(inputs, world=8, total=2048):
+    ranks = [1 + (m % 20) for m in range(total)]
+    base = inputs.model_factors(MODES, ranks, 1)
+    jk = [(0, m % MODES[0]) for m in range(total)]
+    for (fs, _), (mode, fiber) in zip(base, jk):
+        fs[mode][fiber, :] *= 0.0  # Ktensor::fill zeroes the jk fiber (ktensor.cpp:21-30)
+    return base, jk
+
+
+def test_c5_shard_jackknife_vs_oracle(cc, oracle, inputs):
+    """GPU 0's shard of config 5: models m = 0, 8, 16, ... (256 of them), each jk = (0, m mod 300)."""
+    iters = 6
+    X = inputs.tensor(MODES, 0)
+    base_all, jk_all = _c5_models(inputs)
+    base, jk = base_all[0::8], jk_all[0::8]
+    assert len(base) == 256
+    prm = cc.default_params(max_iterations=iters, force_max_iter=1, line_search=1, line_search_interval=5,
+                            line_search_step=0.0)
+    e, gm = _engine(cc, X, base, prm, jk=jk)
+    rep = e.run()
+    e.close()
+    assert rep.iter == iters
+    th = _threads()
+    oracle.use_mkl(th)
+    oracle.set_threads(th)
+    try:
+        om = [oracle.Model([f.copy() for f in fs], lam.copy(), jk=j) for (fs, lam), j in zip(base, jk)]
+        orep = oracle.cp_cals(X, MODES, om, oracle.default_params(
+            max_iterations=iters, force_max_iter=1, buffer_size=sum(m.rank for m in om),
+            mttkrp_method=oracle.MTTKRP, line_search=1, line_search_interval=5, threads=th))
+    finally:
+        oracle.use_own_gemm()
+        oracle.set_threads(1)
+    assert (rep.iter, rep.ls_performed, rep.ls_failed) == (orep.iter, orep.ls_performed, orep.ls_failed)
+    _compare(gm, om)
+    for g, (mode, fiber) in zip(gm, jk):
+        assert not g.factors[mode][fiber, :].any(), "jk fiber row must be exactly zero"
+
+
+def test_c5_all_2048_models_on_one_engine(cc, inputs):
+    """The N = 1 point of config 5 (R = 21 456 columns, T = 15.7 GB): every 8th model must be the one
+    GPU 0's shard engine fits (other column positions => other split-K teams: <= 1e-10, not bitwise);
+    jk rows exactly zero; the jk fast error uses ||X without slice i|| (cals.cpp:291-296)."""
+    sweeps = 2
+    X = inputs.tensor(MODES, 0)
+    base_all, jk_all = _c5_models(inputs)
+    prm = cc.default_params(max_iterations=sweeps, force_max_iter=1, line_search=1, line_search_interval=5,
+                            line_search_step=0.0)
+    e, gm = _engine(cc, X, base_all, prm, jk=jk_all)
+    assert e.admit() == 2048 and e.active_cols == 21456 and e.models_in_flight == 2048
+    rep = e.run()
+    e.close()
+    assert rep.iter == sweeps
+    es, gs = _engine(cc, X, base_all[0::8], prm, jk=jk_all[0::8])
+    es.run()
+    es.close()
+    worst = 0.0
+    for a, b in zip(gm[0::8], gs):
+        assert a.iters == b.iters
+        for fa, fb in zip(a.factors, b.factors):
+            worst = max(worst, rel(fa, fb))
+        assert abs(a.error - b.error) <= 1e-10 * max(1.0, b.error)
+    assert worst < 1e-10, worst
+    for g, (mode, fiber) in zip(gm, jk_all):
+        assert not g.factors[mode][fiber, :].any()
+    X3 = X.reshape(MODES, order="F")
+    for k in (7, 1000, 2047):
+        g, (_, fiber) = gm[k], jk_all[k]
+        R3 = reconstruct(g.factors, g.lam, MODES).reshape(MODES, order="F")
+        keep = np.arange(MODES[0]) != fiber
+        slow = np.linalg.norm((X3 - R3)[keep])
+        assert abs(g.error - slow) <= 1e-9 * slow

@@ -282,7 +282,27 @@ def test_cli_driver_runs(extra):
     # two separate assertions: a crash at process exit (seen once: -11 after all output)
     # must be told apart from a run that did not finish
     assert "Speedup:" in r.stdout, "driver did not finish: rc=%s stderr=%s" % (r.returncode, r.stderr[-400:])
-    assert r.returncode == 0, "driver finished but exited with rc=%s stderr=%s" % (r.returncode, r.stderr[-400:])
+    # the driver installs crash_trace: a fatal signal, also one during process teardown, leaves its
+    # backtrace on stderr
+    assert r.returncode == 0, "driver finished but exited with rc=%s stderr=%s" % (r.returncode, r.stderr[-4000:])
+
+
+def test_cli_driver_reads_tensor_file(tmp_path):
+    """driver -f FILE: Tensor(file_name) (src/tensor.cpp:35-65: first line = mode sizes separated by
+    blanks, then one value per line, mode 0 fastest) feeding cp_cals."""
+    import subprocess
+    modes = [9, 8, 7]
+    rng = np.random.default_rng(3)
+    vals = rng.uniform(-1, 1, int(np.prod(modes)))
+    path = tmp_path / "tensor.txt"
+    path.write_text(" ".join(map(str, modes)) + "\n" + "\n".join(repr(float(v)) for v in vals) + "\n")
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cp-cals_amd", "examples", "driver")
+    r = subprocess.run([exe, "-f", str(path), "-c", "1:3:2"], capture_output=True, text=True, timeout=300)
+    print(r.stdout, r.stderr)
+    assert "Tensor read from" in r.stdout and "9-8-7" in r.stdout and "Speedup:" in r.stdout
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([exe, "-f", str(tmp_path / "missing.txt")], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 2 and "cannot open" in r.stderr
 
 
 # ---- full-size properties (BASELINE configs 2 and 3): no oracle run, exact identities instead ----

@@ -31,7 +31,12 @@ def _worker(rank, world, port, q):
     dist.all_gather_object(gathered, mine)
     sharding.barrier()
     rate, t = sharding.aggregate_rate(local_units=10 * (rank + 1), local_seconds=1.0 + rank)
-    q.put((rank, mine, gathered, rate, t))
+    # config 5 (strong scaling): the job's 2048 models split m -> rank m mod N; one step = one sweep of
+    # the whole job, so job rate = steps / slowest rank (bench.py --workload c5)
+    c5 = sharding.shard_round_robin(2048, world, rank)
+    srate, st = sharding.strong_rate(job_steps=50, local_seconds=2.0 + 0.5 * rank)
+    per_rank = sharding.gather_over_ranks(2.0 + 0.5 * rank)
+    q.put((rank, mine, gathered, rate, t, len(c5), c5[:3], srate, st, per_rank))
     dist.destroy_process_group()
 
 
@@ -54,6 +59,9 @@ def test_round_robin_shards_and_aggregation_world2():
         assert r[2] == [res[0][1], res[1][1]]
         assert abs(r[3] - 30.0 / 2.0) < 1e-12          # (10 + 20) units / max(1 s, 2 s)
         assert abs(r[4] - 2.0) < 1e-12
+        assert r[5] == 1024 and r[6] == [r[0], r[0] + 2, r[0] + 4]
+        assert abs(r[7] - 50 / 2.5) < 1e-12 and abs(r[8] - 2.5) < 1e-12   # steps / max-over-ranks time
+        assert r[9] == [2.0, 2.5]
 
 
 def _queue_worker(rank, world, port, q):
