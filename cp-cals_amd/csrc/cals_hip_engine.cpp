@@ -84,7 +84,8 @@ double now_ms() {
 struct cals_hip_engine {
   int n_modes = 0;
   int64_t modes[CALS_HIP_MAX_MODES] = {0};
-  int64_t buffer = 0;
+  int64_t buffer = 0;    // MultiKtensor buffer_size of the current binding (<= capacity)
+  int64_t capacity = 0;  // columns every device buffer was allocated for (cals_hip_rebind)
   int device = 0;
   int n_cu = 256;
   hipStream_t stream = nullptr;
@@ -173,9 +174,18 @@ struct cals_hip_engine {
     int cls;  // 0 mttkrp, 1 update, 2 other, 3 ttm (flops), 4 contract (flops field = bytes)
     size_t ev;
     double flops;
+    int64_t sweep;  // e->sweeps when the launch was recorded
+    int mode;       // mode being updated (-1: outside the mode loop)
+    int kind;       // sweep-log column: see LOG_* below
   };
   std::vector<Rec> recs;
   cals_hip_kernel_stats stats{};
+  // per-sweep log (CalsReport timer matrices, include/cals.h:55-63)
+  bool sweep_log_on = false;
+  int saved_profiling = 0;
+  int64_t log_base = 0;  // e->sweeps of the first logged sweep
+  std::vector<cals_hip_sweep_record> sweep_log;
+  int cur_mode = -1;
 };
 
 namespace {
@@ -280,7 +290,8 @@ void compress_plan(const int64_t *occ, int64_t n, std::vector<std::pair<int64_t,
 }
 
 // ---- profiling helpers ----
-int prof_begin(cals_hip_engine *e, int cls, double flops) {
+enum { LOG_NONE = -1, LOG_FUSED = 0, LOG_UPDATE, LOG_TTM, LOG_CONTRACT, LOG_KRP, LOG_LS };
+int prof_begin(cals_hip_engine *e, int cls, double flops, int kind = LOG_NONE) {
   if (!e->profiling) return -1;
   // level 2: only the MFMA kernels and the contraction (classes 0, 3, 4).  An event pair is two more
   // packets on the queue and keeps the next launch from overlapping the kernel's tail: around all 13
@@ -294,7 +305,7 @@ int prof_begin(cals_hip_engine *e, int cls, double flops) {
   }
   const size_t k = e->ev_used++;
   (void)hipEventRecord(e->ev_pool[k].a, e->stream);
-  e->recs.push_back({cls, k, flops});
+  e->recs.push_back({cls, k, flops, e->sweeps, e->cur_mode, kind});
   return (int)k;
 }
 void prof_end(cals_hip_engine *e, int k) {
@@ -306,6 +317,19 @@ void prof_collect(cals_hip_engine *e) {
   for (auto &r : e->recs) {
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, e->ev_pool[r.ev].a, e->ev_pool[r.ev].b) != hipSuccess) continue;
+    if (e->sweep_log_on && r.kind != LOG_NONE && r.sweep >= e->log_base &&
+        (size_t)(r.sweep - e->log_base) < e->sweep_log.size()) {
+      cals_hip_sweep_record &L = e->sweep_log[(size_t)(r.sweep - e->log_base)];
+      const int m = (r.mode >= 0 && r.mode < CALS_HIP_MAX_MODES) ? r.mode : 0;
+      switch (r.kind) {
+        case LOG_FUSED: L.fused_ms[m] += ms; L.mttkrp_ms[m] += ms; L.flops += r.flops; break;
+        case LOG_TTM: L.ttm_ms[m] += ms; L.mttkrp_ms[m] += ms; L.flops += r.flops; break;
+        case LOG_CONTRACT: L.contract_ms[m] += ms; L.mttkrp_ms[m] += ms; break;
+        case LOG_KRP: L.krp_ms[m] += ms; L.mttkrp_ms[m] += ms; break;
+        case LOG_UPDATE: L.update_ms[m] += ms; break;
+        case LOG_LS: L.ls_ms += ms; break;
+      }
+    }
     if (r.cls == 0) {
       e->stats.mttkrp_launches++;
       e->stats.mttkrp_ms += ms;
@@ -350,12 +374,12 @@ int alloc_ls(cals_hip_engine *e) {
   if (e->ls_allocated) return CALS_HIP_OK;
   for (int n = 0; n < e->n_modes; n++) {
     int rc;
-    if ((rc = dev_alloc_elems(e, &e->prev[n], (size_t)(e->modes[n] * e->buffer)))) return rc;
-    if ((rc = dev_alloc_elems(e, &e->backup[n], (size_t)(e->modes[n] * e->buffer)))) return rc;
+    if ((rc = dev_alloc_elems(e, &e->prev[n], (size_t)(e->modes[n] * e->capacity)))) return rc;
+    if ((rc = dev_alloc_elems(e, &e->backup[n], (size_t)(e->modes[n] * e->capacity)))) return rc;
   }
   int rc;
-  if ((rc = dev_alloc(e, &e->prev_lambda, (size_t)e->buffer))) return rc;
-  if ((rc = dev_alloc(e, &e->backup_lambda, (size_t)e->buffer))) return rc;
+  if ((rc = dev_alloc(e, &e->prev_lambda, (size_t)e->capacity))) return rc;
+  if ((rc = dev_alloc(e, &e->backup_lambda, (size_t)e->capacity))) return rc;
   e->ls_allocated = true;
   return CALS_HIP_OK;
 }
@@ -366,16 +390,16 @@ int alloc_nnls(cals_hip_engine *e) {
     int64_t imax = 1;
     for (int n = 0; n < e->n_modes; n++) {
       imax = std::max(imax, e->modes[n]);
-      if ((rc = dev_alloc(e, &e->act[n], (size_t)(e->modes[n] * e->buffer)))) return rc;
+      if ((rc = dev_alloc(e, &e->act[n], (size_t)(e->modes[n] * e->capacity)))) return rc;
     }
-    if ((rc = dev_alloc(e, &e->rowdot, (size_t)(imax * e->max_slots)))) return rc;
+    if ((rc = dev_alloc(e, &e->rowdot, (size_t)(imax * std::min<int64_t>(e->capacity, 1 << 20))))) return rc;
     if ((rc = dev_alloc(e, &e->d_nnls_status, 1))) return rc;
     HIPCHK(hipMemsetAsync(e->d_nnls_status, 0, sizeof(int), e->stream));
     e->nnls_allocated = true;
   }
   if (e->prm.line_search && !e->nnls_ls_allocated) {
     for (int n = 0; n < e->n_modes; n++)
-      if ((rc = dev_alloc(e, &e->act_backup[n], (size_t)(e->modes[n] * e->buffer)))) return rc;
+      if ((rc = dev_alloc(e, &e->act_backup[n], (size_t)(e->modes[n] * e->capacity)))) return rc;
     e->nnls_ls_allocated = true;
   }
   return CALS_HIP_OK;
@@ -456,7 +480,7 @@ int launch_mttkrp(cals_hip_engine *e, int mode, int64_t R, Geo *geo_out, void *c
     k.R = (int)R;
     k.Q = e->krp_ws;
     k.dtype = e->dtype;
-    const int pk = prof_begin(e, 2, 0);
+    const int pk = prof_begin(e, 2, 0, LOG_KRP);
     HIPCHK(krp_launch(k, e->stream));
     prof_end(e, pk);
     Q = e->krp_ws;
@@ -489,7 +513,7 @@ int launch_mttkrp(cals_hip_engine *e, int mode, int64_t R, Geo *geo_out, void *c
     return fail(e, CALS_HIP_ERR_STATE, "internal: partial buffer too small");
   double total = 1.0;
   for (int n = 0; n < e->n_modes; n++) total *= (double)e->modes[n];
-  const int pk = prof_begin(e, 0, 2.0 * total * (double)R);
+  const int pk = prof_begin(e, 0, 2.0 * total * (double)R, LOG_FUSED);
   HIPCHK(mttkrp3_launch(L.MT, L.m_blocks, a, e->stream));
   prof_end(e, pk);
   if (geo_out) *geo_out = g;
@@ -552,7 +576,7 @@ int launch_ttm(cals_hip_engine *e, int first, int64_t R, Geo *geo_out) {
   const ModeLayout &L = e->lay[first];
   const Geo g = tree_geometry(e, first, R);
   {
-    const int pk = prof_begin(e, 2, 0);
+    const int pk = prof_begin(e, 2, 0, LOG_TTM);
     HIPCHK(pack_pt_launch(e->factor[am], e->modes[am], L.A, L.Ap, g.NB, (int)R, tp.Pt, e->dtype,
                           e->stream));
     prof_end(e, pk);
@@ -584,7 +608,7 @@ int launch_ttm(cals_hip_engine *e, int first, int64_t R, Geo *geo_out) {
     return fail(e, CALS_HIP_ERR_STATE, "internal: partial buffer too small");
   double total = 1.0;
   for (int n = 0; n < e->n_modes; n++) total *= (double)e->modes[n];
-  const int pk = prof_begin(e, 3, 2.0 * total * (double)R);
+  const int pk = prof_begin(e, 3, 2.0 * total * (double)R, LOG_TTM);
   HIPCHK(ttm_launch(a, e->stream));
   prof_end(e, pk);
   tp.t_first = first;
@@ -600,7 +624,7 @@ int launch_contract(cals_hip_engine *e, int64_t R, void *out) {
   const int first = tp.t_first, second = tp.t_second;
   const ModeLayout &L = e->lay[first];
   const double bytes = (double)R * (double)L.S * (double)L.Mp * (double)e->es;
-  const int pk = prof_begin(e, 4, bytes);
+  const int pk = prof_begin(e, 4, bytes, LOG_CONTRACT);
   HIPCHK(contract_launch(tp.Tbuf, L.S, L.Mp, (int)e->modes[first], e->factor[first],
                          e->modes[first], out, e->modes[second], (int)R, e->dtype, e->stream));
   prof_end(e, pk);
@@ -651,13 +675,21 @@ int sweep_once(cals_hip_engine *e, bool evict_enabled, bool defer_changed = fals
   if (e->prm.line_search) {
     if ((rc = alloc_ls(e))) return rc;
     LsArgs la = make_ls_args(e);
-    const int pk = prof_begin(e, 2, 0);
+    const int pk = prof_begin(e, 2, 0, LOG_LS);
     HIPCHK(ls_snapshot_launch(la, e->stream));
     prof_end(e, pk);
   }
   int rank_max = 1;  // sizes the update kernel's LDS panel
   for (auto t : e->registry) rank_max = std::max(rank_max, (int)e->models[t].rank);
+  if (e->sweep_log_on) {
+    cals_hip_sweep_record rec{};
+    rec.cols = R;
+    rec.models = ns;
+    e->sweep_log.resize((size_t)(e->sweeps - e->log_base) + 1, cals_hip_sweep_record{});
+    e->sweep_log.back() = rec;
+  }
   for (int n = 0; n < e->n_modes; n++) {
+    e->cur_mode = n;
     Geo g{0, 0};
     const bool by_contract = e->tree.on && e->tree.t_second == n;
     if (by_contract) {
@@ -691,7 +723,7 @@ int sweep_once(cals_hip_engine *e, bool evict_enabled, bool defer_changed = fals
     u.X_norm = e->X_norm;
     u.jk_norms = e->d_jk_norms;
     u.dbg_trace = e->dbg_trace ? e->dbg_trace + 16 * 2048 - 64 : nullptr;  // last 64 entries of the trace
-    const int pk = prof_begin(e, 1, 0);
+    const int pk = prof_begin(e, 1, 0, LOG_UPDATE);
     if (!by_contract)
       HIPCHK(reduce_partials_launch(e->partial, g.T, e->lay[n].ldPart, (int)e->modes[n], (int)R,
                                     e->factor[n], e->dtype, e->stream));
@@ -716,9 +748,10 @@ int sweep_once(cals_hip_engine *e, bool evict_enabled, bool defer_changed = fals
     HIPCHK(update_launch(u, rank_max, e->stream));
     prof_end(e, pk);
   }
+  e->cur_mode = -1;
   if (e->prm.line_search) {
     LsArgs la = make_ls_args(e);
-    const int pk = prof_begin(e, 2, 0);
+    const int pk = prof_begin(e, 2, 0, LOG_LS);
     const bool pending = e->tree.t_second >= 0;  // a T shared across the sweep boundary
     if (pending) HIPCHK(hipMemsetAsync(e->tree.d_changed, 0, sizeof(int), e->stream));
     la.changed = pending ? e->tree.d_changed : nullptr;
@@ -1142,6 +1175,19 @@ int admit(cals_hip_engine *e, int64_t *n_admitted) {
   return CALS_HIP_OK;
 }
 
+// host-clock columns of the sweep that just finished (the status read-back in between synchronises the
+// stream, so these are wall times of the loop iteration, like the reference's chrono timers); the
+// device-time columns come from the hipEvent pairs (prof_collect: the stream is idle here)
+void log_host_times(cals_hip_engine *e, double t_start, double t_admitted, double t_status, double t_end) {
+  prof_collect(e);
+  const int64_t k = e->sweeps - 1 - e->log_base;
+  if (k < 0 || (size_t)k >= e->sweep_log.size()) return;
+  cals_hip_sweep_record &L = e->sweep_log[(size_t)k];
+  L.admit_ms = t_admitted - t_start;
+  L.defrag_ms = t_end - t_status;
+  L.iteration_ms = t_end - t_start;
+}
+
 // eviction list (src/cals.cpp:336-354) from the fetched status, then remove + compress (:357-362)
 int evict(cals_hip_engine *e, int64_t *n_evicted) {
   std::vector<int64_t> rm;
@@ -1216,6 +1262,7 @@ int cals_hip_create_ex(cals_hip_engine **out, int n_modes, const int64_t *modes,
   e->device = device;
   e->n_modes = n_modes;
   e->buffer = buffer_size;
+  e->capacity = buffer_size;
   for (int n = 0; n < n_modes; n++) {
     if (modes[n] < 1 || modes[n] > (1 << 24)) return fail(e, CALS_HIP_ERR_ARG, "bad mode size");
     e->modes[n] = modes[n];
@@ -1402,6 +1449,66 @@ int cals_hip_create_ex(cals_hip_engine **out, int n_modes, const int64_t *modes,
   HIPCHK(hipStreamSynchronize(e->stream));
   note_device_used(device);
   return CALS_HIP_OK;
+}
+
+// The next cp_cals call on the same tensor: MultiKtensor is constructed anew (src/cals.cpp:117) while
+// the Tensor keeps its device mirror (include/tensor.h:56-59, src/cals.cpp:144-147).  Here: the engine
+// keeps its X copies, plan and device buffers; the packing state starts over.
+int cals_hip_rebind(cals_hip_engine *e, int64_t buffer_size) {
+  if (!e) return CALS_HIP_ERR_ARG;
+  if (buffer_size < 1) return fail(e, CALS_HIP_ERR_ARG, "buffer_size must be >= 1");
+  if (!e->queue.empty() || !e->registry.empty())
+    return fail(e, CALS_HIP_ERR_STATE, "cals_hip_rebind: models are queued or in flight");
+  if (buffer_size > e->capacity)
+    return fail(e, CALS_HIP_ERR_FULL, "cals_hip_rebind: buffer_size exceeds the engine's capacity");
+  (void)hipSetDevice(e->device);
+  int rc = flush_pending_out(e);
+  if (rc) return rc;
+  HIPCHK(hipStreamSynchronize(e->stream));
+  prof_collect(e);
+  e->arena_off = 0;
+  e->buffer = buffer_size;
+  e->models.clear();
+  e->occ.assign((size_t)buffer_size, 0);
+  e->unique_id = 1;
+  e->flag_jk = false;
+  e->max_slots = (int)std::min<int64_t>(buffer_size, 1 << 20);
+  e->free_slots.clear();
+  for (int s = e->max_slots - 1; s >= 0; s--) e->free_slots.push_back(s);
+  e->slots_dirty = true;
+  e->n_ktensors = e->comp_sum = e->ls_performed = e->ls_failed = 0;
+  e->changed_deferred = false;
+  tree_invalidate(e);
+  adjust_edges(e);
+  return CALS_HIP_OK;
+}
+
+int64_t cals_hip_capacity(const cals_hip_engine *e) { return e ? e->capacity : 0; }
+
+int cals_hip_set_sweep_log(cals_hip_engine *e, int enabled) {
+  if (!e) return CALS_HIP_ERR_ARG;
+  (void)hipSetDevice(e->device);
+  prof_collect(e);
+  if (enabled && !e->sweep_log_on) {
+    e->saved_profiling = e->profiling;
+    e->profiling = 1;  // the device-time columns need an event pair around every launch
+    e->log_base = e->sweeps;
+    e->sweep_log.clear();
+    e->sweep_log_on = true;
+  } else if (!enabled && e->sweep_log_on) {
+    e->profiling = e->saved_profiling;
+    e->sweep_log_on = false;
+  }
+  return CALS_HIP_OK;
+}
+
+int64_t cals_hip_get_sweep_log(cals_hip_engine *e, cals_hip_sweep_record *out, int64_t max_records) {
+  if (!e) return 0;
+  (void)hipSetDevice(e->device);
+  prof_collect(e);
+  const int64_t n = (int64_t)e->sweep_log.size();
+  for (int64_t k = 0; out && k < n && k < max_records; k++) out[k] = e->sweep_log[(size_t)k];
+  return n;
 }
 
 int cals_hip_destroy(cals_hip_engine *e) {
@@ -1622,8 +1729,10 @@ int cals_hip_step(cals_hip_engine *e, int64_t *n_admitted, int64_t *n_evicted) {
   if (n_admitted) *n_admitted = 0;
   if (n_evicted) *n_evicted = 0;
   if (e->queue.empty() && e->registry.empty()) return CALS_HIP_OK;
+  const double it0 = e->sweep_log_on ? now_ms() : 0.0;
   int rc = admit(e, n_admitted);
   if (rc) return rc;
+  const double it1 = e->sweep_log_on ? now_ms() : 0.0;
   if ((rc = sweep_once(e, true, true))) return rc;
   // models evicted by the previous step land in their callers' storage while this sweep runs; the
   // ones evicted by this step follow at the next step, cals_hip_model_result or cals_hip_synchronize
@@ -1635,7 +1744,10 @@ int cals_hip_step(cals_hip_engine *e, int64_t *n_admitted, int64_t *n_evicted) {
       if (f & 1) e->ls_performed++;
       if (f & 2) e->ls_failed++;
     }
-  return evict(e, n_evicted);
+  const double it2 = e->sweep_log_on ? now_ms() : 0.0;
+  rc = evict(e, n_evicted);
+  if (!rc && e->sweep_log_on) log_host_times(e, it0, it1, it2, now_ms());
+  return rc;
 }
 
 // counters accumulated since the last cals_hip_run / cals_hip_reset (iter = sweeps, times = 0)
@@ -1676,8 +1788,10 @@ int cals_hip_run(cals_hip_engine *e, cals_hip_report *rep) {
   if (timing) tl = now_ms();
   while (!converged) {
     iter++;
+    const double it0 = e->sweep_log_on ? now_ms() : 0.0;
     int rc = admit(e, nullptr);
     if (rc) return rc;
+    const double it1 = e->sweep_log_on ? now_ms() : 0.0;
     lap(0);
     if ((rc = sweep_once(e, true, true))) return rc;
     // the models evicted after the previous sweep reach their callers' storage while this one runs
@@ -1691,8 +1805,10 @@ int cals_hip_run(cals_hip_engine *e, cals_hip_report *rep) {
         if (f & 1) e->ls_performed++;
         if (f & 2) e->ls_failed++;
       }
+    const double it2 = e->sweep_log_on ? now_ms() : 0.0;
     if ((rc = evict(e, nullptr))) return rc;
     lap(3);
+    if (e->sweep_log_on) log_host_times(e, it0, it1, it2, now_ms());
     converged = e->queue.empty() && e->registry.empty();
   }
   {

@@ -94,6 +94,28 @@ typedef struct {
   double contract_bytes;
 } cals_hip_kernel_stats;
 
+/* One record per outer sweep of cals_hip_run / cals_hip_step while the sweep log is on: what the
+ * reference keeps in CalsReport::{als_times, mode_times, mttkrp_times, flops_per_iteration, cols}
+ * (include/cals.h:55-63, filled at src/cals.cpp:213-217, 269-275, 367-370).  Host-clock columns are
+ * wall times of the loop iteration (the per-sweep status read-back synchronises the stream); device
+ * columns are sums of hipEvent pairs around the launches, per mode being updated. */
+typedef struct {
+  int64_t cols;          /* CalsReport::cols: active columns of the multi-factors */
+  int64_t models;        /* models in flight */
+  double flops;          /* 2 * prod(modes) * cols per MFMA-kernel launch (fused MTTKRP or TTM), summed */
+  double iteration_ms;   /* ALS_TIMERS::ITERATION (host clock: admission .. compress) */
+  double admit_ms;       /* host clock: admission phase (enqueue only; the copies run asynchronously) */
+  double defrag_ms;      /* ALS_TIMERS::DEFRAGMENTATION: eviction + compress (host clock) */
+  double ls_ms;          /* ALS_TIMERS::LINE_SEARCH: snapshot + line-search kernels (device) */
+  double mttkrp_ms[CALS_HIP_MAX_MODES];   /* MODE_TIMERS::MTTKRP per mode = fused + ttm + contract + krp */
+  double update_ms[CALS_HIP_MAX_MODES];   /* MODE_TIMERS::UPDATE per mode: reduce + (NNLS) + update kernel
+                                           * (the fast error of ALS_TIMERS::ERROR is fused into the last mode's) */
+  double fused_ms[CALS_HIP_MAX_MODES];    /* MTTKRP_TIMERS::MT_GEMM: the fused MTTKRP kernel */
+  double ttm_ms[CALS_HIP_MAX_MODES];      /* MTTKRP_TIMERS::TS_GEMM: the TTM (+ its operand packing) */
+  double contract_ms[CALS_HIP_MAX_MODES]; /* MTTKRP_TIMERS::TS_GEMV: the contraction of T */
+  double krp_ms[CALS_HIP_MAX_MODES];      /* MTTKRP_TIMERS::MT_KRP: Khatri-Rao of the streamed modes (N > 3) */
+} cals_hip_sweep_record;
+
 void cals_hip_default_params(cals_hip_params *p);
 
 /* ---- lifetime ---- */
@@ -122,6 +144,14 @@ int cals_hip_dtype(const cals_hip_engine *e);
  * step, an eviction or an admission made stale is dropped and recomputed.  Chosen by a cost model;
  * CALS_HIP_TREE=0|A|B|M in the environment at create overrides it. */
 int cals_hip_tree(const cals_hip_engine *e);
+/* Re-targets an IDLE engine (nothing queued or in flight) at another buffer_size <= the capacity it
+ * was created with: same tensor copies in HBM, same plan, same device buffers, fresh packing state
+ * (occupancy, ids, tickets restart at 0).  Replaces: the next cp_cals call constructing its
+ * MultiKtensor (src/cals.cpp:117) while the Tensor keeps its device mirror (include/tensor.h:56-59,
+ * src/cals.cpp:144-147: X is uploaded only when it has no device copy yet).  CALS_HIP_ERR_FULL when
+ * buffer_size exceeds the capacity, CALS_HIP_ERR_STATE when models are queued or in flight. */
+int cals_hip_rebind(cals_hip_engine *e, int64_t buffer_size);
+int64_t cals_hip_capacity(const cals_hip_engine *e); /* buffer_size the engine was created with */
 int cals_hip_destroy(cals_hip_engine *e);
 const char *cals_hip_last_error(const cals_hip_engine *e);
 
@@ -222,6 +252,10 @@ int cals_hip_get_kernel_stats(cals_hip_engine *e, cals_hip_kernel_stats *out);
 int cals_hip_reset_kernel_stats(cals_hip_engine *e);
 /* hipStream_t the engine launches on (as void*), so callers can bracket it with their own events */
 void *cals_hip_stream(cals_hip_engine *e);
+/* Per-sweep log for CalsReport's timer matrices: on = an event pair around every launch (profiling
+ * level 1) and one record per sweep; get returns the number of records (copies at most max_records). */
+int cals_hip_set_sweep_log(cals_hip_engine *e, int enabled);
+int64_t cals_hip_get_sweep_log(cals_hip_engine *e, cals_hip_sweep_record *out, int64_t max_records);
 /* diagnostics (CALS_MTTKRP_CLOCK=1 in the environment at create): median over workgroups of the
  * shader cycles a MTTKRP workgroup ran and of the clock (GHz) it saw (s_memtime / s_memrealtime) */
 int cals_hip_debug_clock(cals_hip_engine *e, int n_workgroups, double *cycles_median, double *ghz_median);
