@@ -46,6 +46,17 @@ class ModelStatus(C.Structure):
                 ("approx_error", C.c_double), ("evicted", C.c_int)]
 
 
+class SweepRecord(C.Structure):
+    """cals_hip_sweep_record: one outer sweep of run()/step() while the sweep log is on."""
+    _fields_ = [
+        ("cols", C.c_int64), ("models", C.c_int64), ("flops", C.c_double), ("iteration_ms", C.c_double),
+        ("admit_ms", C.c_double), ("defrag_ms", C.c_double), ("ls_ms", C.c_double),
+        ("mttkrp_ms", C.c_double * MAX_MODES), ("update_ms", C.c_double * MAX_MODES),
+        ("fused_ms", C.c_double * MAX_MODES), ("ttm_ms", C.c_double * MAX_MODES),
+        ("contract_ms", C.c_double * MAX_MODES), ("krp_ms", C.c_double * MAX_MODES),
+    ]
+
+
 class KernelStats(C.Structure):
     _fields_ = [
         ("mttkrp_launches", C.c_int64), ("mttkrp_ms", C.c_double), ("mttkrp_flops", C.c_double),
@@ -69,6 +80,7 @@ EXPORTS = [
     "cals_hip_debug_get_norms", "cals_hip_set_profiling", "cals_hip_get_kernel_stats",
     "cals_hip_reset_kernel_stats", "cals_hip_stream", "cals_hip_device_count",
     "cals_hip_create_ex", "cals_hip_dtype", "cals_hip_tree", "cals_hip_set_tensor_f32",
+    "cals_hip_rebind", "cals_hip_capacity", "cals_hip_set_sweep_log", "cals_hip_get_sweep_log",
     "cals_hip_debug_clock", "cals_hip_debug_ttm_trace", "cals_hip_host_first_fit", "cals_hip_host_compress_plan", "cals_hip_host_active_cols",
 ]
 
@@ -90,6 +102,12 @@ def load_library():
     lib.cals_hip_dtype.argtypes = [vp]
     lib.cals_hip_debug_ttm_trace.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int]
     lib.cals_hip_tree.argtypes = [vp]
+    lib.cals_hip_rebind.argtypes = [vp, i64]
+    lib.cals_hip_capacity.argtypes = [vp]
+    lib.cals_hip_capacity.restype = i64
+    lib.cals_hip_set_sweep_log.argtypes = [vp, C.c_int]
+    lib.cals_hip_get_sweep_log.argtypes = [vp, C.POINTER(SweepRecord), i64]
+    lib.cals_hip_get_sweep_log.restype = i64
     lib.cals_hip_set_tensor_f32.argtypes = [vp, C.POINTER(C.c_float)]
     lib.cals_hip_destroy.argtypes = [vp]
     lib.cals_hip_last_error.argtypes = [vp]
@@ -218,6 +236,24 @@ class Engine:
             self.close()
         except Exception:
             pass
+
+    def rebind(self, buffer_size):
+        """Re-target the idle engine at another buffer_size <= capacity (same X copies, fresh packing)."""
+        self._chk(self.lib.cals_hip_rebind(self.h, int(buffer_size)))
+        self._models = []
+
+    @property
+    def capacity(self):
+        return int(self.lib.cals_hip_capacity(self.h))
+
+    def set_sweep_log(self, on):
+        self._chk(self.lib.cals_hip_set_sweep_log(self.h, 1 if on else 0))
+
+    def sweep_log(self):
+        n = self.lib.cals_hip_get_sweep_log(self.h, None, 0)
+        arr = (SweepRecord * max(int(n), 1))()
+        self.lib.cals_hip_get_sweep_log(self.h, arr, n)
+        return list(arr)[:n]
 
     def set_tensor(self, X):
         X = np.asarray(X)

@@ -6,6 +6,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcals_hip.so")
 SOURCES = ["mttkrp_kernel_v3.hip", "ttm_kernel.hip", "model_kernels.hip", "nnls_kernel.hip", "cals_hip_engine.cpp"]
+API_SOURCES = ["cals.cpp", "als.cpp", "tensor.cpp", "ktensor.cpp", "multi_ktensor.cpp", "utils.cpp"]
 HEADERS = ["cals_hip_internal.h", "mfma_common.h", os.path.join("..", "..", "include", "cals_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-Wall", "-Wno-unused-result"]
 
@@ -49,11 +50,15 @@ def build(force=False, verbose=False):
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
-    # C++ host layer (cals::cp_cals & value classes) over the C ABI
-    api_src = os.path.join(HERE, "cals", "cals.cpp")
+    # C++ host layer (the reference's header set: cals::cp_cals, Tensor / Matrix / Ktensor / MultiKtensor,
+    # cp_als ..., utils) over the C ABI
+    api_dir = os.path.join(HERE, "cals")
+    api_srcs = [os.path.join(api_dir, f) for f in API_SOURCES]
+    api_hdrs = [os.path.join(dp, f) for dp, _, fs in os.walk(api_dir) for f in fs if f.endswith(".h")]
     api_lib = os.path.join(HERE, "libcals.so")
-    if force or _newer(api_lib, [api_src, os.path.join(HERE, "cals", "cals.h"), LIB]):
-        cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-fPIC", "-pthread", "-shared", "-o", api_lib, api_src,
+    if force or _newer(api_lib, api_srcs + api_hdrs + [LIB, os.path.join(HERE, "..", "include", "cals_hip.h")]):
+        cmd = ["g++", "-std=c++17", "-O2", "-g", "-Wall", "-Wextra", "-fPIC", "-pthread", "-shared", "-I" + api_dir,
+               "-I" + os.path.join(api_dir, "utils"), "-o", api_lib] + api_srcs + [
                "-L" + HERE, "-lcals_hip", "-Wl,-rpath,$ORIGIN"]
         if verbose:
             print(" ".join(cmd))

@@ -1,87 +1,61 @@
-// cals::cp_cals over the C ABI (include/cals_hip.h).  Reference boundary: include/cals.h:196,
-// body src/cals.cpp:19-395.
+// cals::cp_cals / jk_cp_cals over the C ABI (include/cals_hip.h).  Reference boundary: include/cals.h:196,
+// body src/cals.cpp:19-446.  All numerics run in libcals_hip.so; this file moves pointers, parameters and
+// results across the boundary and keeps X's device copies alive between calls (DeviceMirror).
 #include "cals.h"
 
-#include <algorithm>
+#include <array>
 #include <atomic>
 #include <chrono>
+#include <cstring>
 #include <exception>
-#include <limits>
+#include <mutex>
+#include <stdexcept>
 #include <thread>
 
 #include "../../include/cals_hip.h"
 
 namespace cals {
 
-void CalsParams::print() const {
-  using std::cout;
-  using std::endl;
-  cout << "---------------------------------------" << endl;
-  cout << "CALS parameters" << endl;
-  cout << "---------------------------------------" << endl;
-  cout << "Tol:             " << tol << endl;
-  cout << "Max Iterations:  " << max_iterations << endl;
-  cout << "Buffer Size:     " << buffer_size << endl;
-  cout << "Line Search:     " << (line_search ? "true" : "false") << endl;
-  if (line_search) cout << "-Line Search Interval: " << line_search_interval << " iterations" << endl;
-  cout << "Device path:     MI355X HIP engine (device";
-  if (devices.empty())
-    cout << " " << device;
-  else
-    for (int d : devices) cout << " " << d;
-  cout << ", " << (precision == FP32 ? "fp32" : "fp64") << " storage)" << endl;
-  cout << "---------------------------------------" << endl;
-}
-
-double Timer::now() {
-  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
-}
-
-Tensor::Tensor(const std::string &file_name) {
-  std::ifstream file(file_name);
-  if (!file.is_open()) throw std::runtime_error("Tensor: cannot open " + file_name);
-  std::string line;
-  std::getline(file, line);
-  std::stringstream ss(line);
-  dim_t m;
-  while (ss >> m) modes.push_back(m);
-  n_elements = 1;
-  for (auto v : modes) n_elements *= v;
-  owned.reset(new double[n_elements]);
-  data = owned.get();
-  dim_t index = 0;
-  double val;
-  while (index < n_elements && file >> val) data[index++] = val;
-  if (index != n_elements) throw std::runtime_error("Tensor: " + file_name + " holds too few values");
-}
-
-void AlsParams::print() const {
-  using std::cout;
-  using std::endl;
-  cout << "---------------------------------------" << endl;
-  cout << "ALS parameters" << endl;
-  cout << "---------------------------------------" << endl;
-  cout << "Tolerance:        " << tol << endl;
-  cout << "Max Iterations:   " << max_iterations << endl;
-  cout << "Line Search:      " << (line_search ? "true" : "false") << endl;
-  cout << "Device path:      MI355X HIP engine (device " << device << ")" << endl;
-  cout << "---------------------------------------" << endl;
-}
-
-namespace {
-struct EngineGuard {
-  cals_hip_engine *e{nullptr};
-  ~EngineGuard() {
-    if (e) cals_hip_destroy(e);
+// ---------------------------------------------------------------------------------------------
+// DeviceMirror: what Tensor keeps between cp_cals calls (the reference's CUDA path keeps `cudata`,
+// include/tensor.h:56-59, and uploads only when it is null, src/cals.cpp:144-147).  One idle engine per
+// (device, storage type) that has fitted models to this tensor: its padded permuted copies of X, its plan
+// and its device buffers are reused through cals_hip_rebind; only the packing state starts over.
+// ---------------------------------------------------------------------------------------------
+struct DeviceMirror {
+  struct Slot {
+    cals_hip_engine *engine{nullptr};
+    int device{0};
+    int dtype{0};
+    const double *data{nullptr};
+    std::array<double, 34> print{};  // sampled fingerprint of X at upload time
+    bool busy{false};
+  };
+  std::mutex mu;
+  std::vector<Slot> slots;
+  ~DeviceMirror() {
+    for (auto &s : slots)
+      if (s.engine) cals_hip_destroy(s.engine);
   }
 };
+
+namespace {
+
 [[noreturn]] void fail(cals_hip_engine *e, const char *what, int rc) {
   throw std::runtime_error(std::string("cp_cals: ") + what + " failed (" + std::to_string(rc) +
                            "): " + (e ? cals_hip_last_error(e) : "no engine"));
 }
-}  // namespace
 
-namespace {
+std::array<double, 34> fingerprint(const Tensor &X) {
+  std::array<double, 34> f{};
+  const dim_t n = X.get_n_elements();
+  if (n == 0) return f;
+  for (dim_t k = 0; k < 32; k++) f[k] = X[(n - 1) * k / 31];
+  f[32] = (double)n;
+  f[33] = X[n / 2];
+  return f;
+}
+
 cals_hip_params to_hip_params(const CalsParams &p) {
   cals_hip_params hp;
   cals_hip_default_params(&hp);
@@ -97,6 +71,149 @@ cals_hip_params to_hip_params(const CalsParams &p) {
   return hp;
 }
 
+// An engine bound to X with `buffer_size` columns for the duration of one call: borrowed from X's
+// DeviceMirror (created or re-targeted as needed) or, with reuse off, private to the call.
+class EngineLease {
+  std::shared_ptr<DeviceMirror> mirror;  // keeps the mirror alive even if X drops it meanwhile
+  cals_hip_engine *e{nullptr};
+  bool borrowed{false};
+  bool ok{false};
+
+  static cals_hip_engine *build(const Tensor &X, int64_t buffer_size, int device, int dtype) {
+    std::vector<int64_t> modes(X.get_modes().begin(), X.get_modes().end());
+    cals_hip_engine *eng = nullptr;
+    int rc = cals_hip_create_ex(&eng, (int)modes.size(), modes.data(), buffer_size, device, dtype);
+    if (rc == 0) rc = cals_hip_set_tensor(eng, X.get_data());
+    if (rc) {
+      const std::string msg = eng ? cals_hip_last_error(eng) : "no engine";
+      if (eng) cals_hip_destroy(eng);
+      throw std::runtime_error("cp_cals: creating the device engine failed (" + std::to_string(rc) + "): " + msg);
+    }
+    return eng;
+  }
+
+ public:
+  EngineLease(const Tensor &X, int64_t buffer_size, int device, int dtype, bool reuse) {
+    if (!reuse) {
+      e = build(X, buffer_size, device, dtype);
+      return;
+    }
+    static std::mutex create_mu;
+    {
+      std::lock_guard<std::mutex> g(create_mu);
+      if (!X.device_mirror()) X.device_mirror() = std::make_shared<DeviceMirror>();
+      mirror = X.device_mirror();
+    }
+    borrowed = true;
+    const auto print = fingerprint(X);
+    std::lock_guard<std::mutex> g(mirror->mu);
+    mirror->slots.erase(std::remove_if(mirror->slots.begin(), mirror->slots.end(),
+                                       [](const DeviceMirror::Slot &s) { return s.engine == nullptr; }),
+                        mirror->slots.end());
+    for (auto &s : mirror->slots) {
+      if (s.busy || s.device != device || s.dtype != dtype) continue;
+      if (s.data != X.get_data() || s.print != print) {  // X was rewritten behind the mirror: upload again
+        const int rc = cals_hip_set_tensor(s.engine, X.get_data());
+        if (rc) fail(s.engine, "cals_hip_set_tensor", rc);
+        s.data = X.get_data();
+        s.print = print;
+      }
+      if (cals_hip_capacity(s.engine) < buffer_size) {  // this call needs wider buffers: replace the engine
+        cals_hip_destroy(s.engine);
+        s.engine = nullptr;
+        s.engine = build(X, buffer_size, device, dtype);
+      } else {
+        const int rc = cals_hip_rebind(s.engine, buffer_size);
+        if (rc) fail(s.engine, "cals_hip_rebind", rc);
+      }
+      s.busy = true;
+      e = s.engine;
+      return;
+    }
+    DeviceMirror::Slot s;
+    s.engine = build(X, buffer_size, device, dtype);
+    s.device = device;
+    s.dtype = dtype;
+    s.data = X.get_data();
+    s.print = print;
+    s.busy = true;
+    mirror->slots.push_back(s);
+    e = s.engine;
+  }
+  EngineLease(const EngineLease &) = delete;
+  EngineLease &operator=(const EngineLease &) = delete;
+  void done() { ok = true; }  // the run finished: the engine is idle and reusable
+  cals_hip_engine *get() const { return e; }
+  ~EngineLease() {
+    if (!e) return;
+    if (!borrowed) {
+      cals_hip_destroy(e);
+      return;
+    }
+    std::lock_guard<std::mutex> g(mirror->mu);
+    for (auto &s : mirror->slots)
+      if (s.engine == e) {
+        if (ok) {
+          s.busy = false;
+        } else {  // an error left the engine in an unknown state: do not hand it out again
+          cals_hip_destroy(e);
+          s.engine = nullptr;
+        }
+      }
+  }
+};
+
+void enqueue_model(cals_hip_engine *e, Ktensor &kt, int64_t *ticket) {
+  std::vector<double *> fptr;
+  for (auto &f : kt.get_factors()) fptr.push_back(f.get_data());
+  const int rc = cals_hip_enqueue(e, (int64_t)kt.get_components(), fptr.data(), kt.get_lambda().data(),
+                                  kt.is_jk() ? (int)kt.get_jk_mode() : -1, (int64_t)kt.get_jk_fiber(), ticket);
+  if (rc) fail(e, "cals_hip_enqueue", rc);
+}
+
+void read_back(cals_hip_engine *e, Ktensor &kt, int64_t ticket) {
+  cals_hip_model_status st;
+  const int rc = cals_hip_model_result(e, ticket, &st);
+  if (rc) fail(e, "cals_hip_model_result", rc);
+  kt.set_iters((dim_t)st.iters);
+  kt.set_approximation_error(st.approx_error);
+  kt.set_fit(st.fit, st.old_fit);
+}
+
+// CalsReport's per-iteration matrices from the engine's sweep log (src/cals.cpp:54-64, 213-217, 269-275,
+// 367-370 fill them from chrono timers around the CPU phases)
+void fill_timers(cals_hip_engine *e, CalsReport &rep) {
+  const int64_t n = cals_hip_get_sweep_log(e, nullptr, 0);
+  std::vector<cals_hip_sweep_record> log((size_t)std::max<int64_t>(n, 1));
+  cals_hip_get_sweep_log(e, log.data(), n);
+  const dim_t its = (dim_t)std::max<int64_t>(n, 1), N = rep.n_modes;
+  rep.als_times = Matrix(AlsTimers::LENGTH, its);
+  rep.mode_times = Matrix(ModeTimers::LENGTH * N, its);
+  rep.mttkrp_times = Matrix(MttkrpTimers::LENGTH * N, its);
+  rep.als_times.zero();
+  rep.mode_times.zero();
+  rep.mttkrp_times.zero();
+  rep.flops_per_iteration.assign(its, 0);
+  rep.cols.assign(its, 0);
+  for (int64_t k = 0; k < n; k++) {
+    const cals_hip_sweep_record &L = log[(size_t)k];
+    const dim_t it = (dim_t)k;
+    rep.cols[it] = (dim_t)L.cols;
+    rep.flops_per_iteration[it] = (uint64_t)L.flops;
+    rep.als_times(AlsTimers::ITERATION, it) = L.iteration_ms * 1e-3;
+    rep.als_times(AlsTimers::DEFRAGMENTATION, it) = L.defrag_ms * 1e-3;
+    rep.als_times(AlsTimers::LINE_SEARCH, it) = L.ls_ms * 1e-3;
+    for (dim_t m = 0; m < N && m < CALS_HIP_MAX_MODES; m++) {
+      rep.mode_times(m * ModeTimers::LENGTH + ModeTimers::MTTKRP, it) = L.mttkrp_ms[m] * 1e-3;
+      rep.mode_times(m * ModeTimers::LENGTH + ModeTimers::UPDATE, it) = L.update_ms[m] * 1e-3;
+      rep.mttkrp_times(m * MttkrpTimers::LENGTH + MttkrpTimers::MT_KRP, it) = L.krp_ms[m] * 1e-3;
+      rep.mttkrp_times(m * MttkrpTimers::LENGTH + MttkrpTimers::MT_GEMM, it) = L.fused_ms[m] * 1e-3;
+      rep.mttkrp_times(m * MttkrpTimers::LENGTH + MttkrpTimers::TS_GEMM, it) = L.ttm_ms[m] * 1e-3;
+      rep.mttkrp_times(m * MttkrpTimers::LENGTH + MttkrpTimers::TS_GEMV, it) = L.contract_ms[m] * 1e-3;
+    }
+  }
+}
+
 // CalsParams::devices with more than one entry: one engine (and one host thread) per device, each
 // with its own replica of X; the models sit behind one shared counter and a device claims a few
 // more whenever none of its claimed models is waiting for buffer columns (the pull-based hand-off
@@ -105,52 +222,47 @@ cals_hip_params to_hip_params(const CalsParams &p) {
 void cp_cals_devices(const Tensor &X, std::vector<std::reference_wrapper<Ktensor>> &all, const CalsParams &p,
                      CalsReport &rep) {
   const size_t n_dev = p.devices.size();
-  std::vector<int64_t> modes(X.get_modes().begin(), X.get_modes().end());
   std::atomic<size_t> next{0};
   std::vector<cals_hip_report> reports(n_dev);
   std::vector<std::exception_ptr> errors(n_dev);
+  const int dtype = p.precision == CalsParams::FP32 ? CALS_HIP_F32 : CALS_HIP_F64;
   auto worker = [&](size_t d) {
     try {
-      EngineGuard g;
-      int rc = cals_hip_create_ex(&g.e, (int)modes.size(), modes.data(), (int64_t)p.buffer_size, p.devices[d],
-                                  p.precision == CalsParams::FP32 ? CALS_HIP_F32 : CALS_HIP_F64);
-      if (rc) fail(g.e, "cals_hip_create", rc);
-      if ((rc = cals_hip_set_tensor(g.e, X.get_data()))) fail(g.e, "cals_hip_set_tensor", rc);
+      EngineLease lease(X, (int64_t)p.buffer_size, p.devices[d], dtype, p.reuse_device_tensor);
+      cals_hip_engine *e = lease.get();
       cals_hip_params hp = to_hip_params(p);
-      if ((rc = cals_hip_set_params(g.e, &hp))) fail(g.e, "cals_hip_set_params", rc);
+      int rc = cals_hip_set_params(e, &hp);
+      if (rc) fail(e, "cals_hip_set_params", rc);
+      if (p.with_time && d == 0) cals_hip_set_sweep_log(e, 1);
       std::vector<std::pair<size_t, int64_t>> mine;  // (index into all, ticket)
       bool drained = false;
       const size_t claim = (size_t)std::max(1, p.claim_models);
       for (;;) {
-        if (!drained && cals_hip_queue_size(g.e) == 0) {
+        if (!drained && cals_hip_queue_size(e) == 0) {
           const size_t lo = next.fetch_add(claim);
           if (lo >= all.size()) drained = true;
           for (size_t i = lo; i < std::min(lo + claim, all.size()); i++) {
-            Ktensor &kt = all[i];
-            std::vector<double *> fptr;
-            for (auto &f : kt.get_factors()) fptr.push_back(f.get_data());
             int64_t ticket = -1;
-            rc = cals_hip_enqueue(g.e, (int64_t)kt.get_components(), fptr.data(), kt.get_lambda().data(),
-                                  kt.is_jk() ? (int)kt.get_jk_mode() : -1, (int64_t)kt.get_jk_fiber(), &ticket);
-            if (rc) fail(g.e, "cals_hip_enqueue", rc);
+            enqueue_model(e, all[i], &ticket);
             mine.emplace_back(i, ticket);
           }
         }
-        if (cals_hip_queue_size(g.e) == 0 && cals_hip_models_in_flight(g.e) == 0) {
+        if (cals_hip_queue_size(e) == 0 && cals_hip_models_in_flight(e) == 0) {
           if (drained) break;
           continue;
         }
-        if ((rc = cals_hip_step(g.e, nullptr, nullptr))) fail(g.e, "cals_hip_step", rc);
+        if ((rc = cals_hip_step(e, nullptr, nullptr))) fail(e, "cals_hip_step", rc);
       }
-      for (auto &m : mine) {
-        cals_hip_model_status st;
-        if ((rc = cals_hip_model_result(g.e, m.second, &st))) fail(g.e, "cals_hip_model_result", rc);
-        Ktensor &kt = all[m.first];
-        kt.set_iters((dim_t)st.iters);
-        kt.set_approximation_error(st.approx_error);
-        kt.set_fit(st.fit, st.old_fit);
+      for (auto &m : mine) read_back(e, all[m.first], m.second);
+      if ((rc = cals_hip_get_report(e, &reports[d]))) fail(e, "cals_hip_get_report", rc);
+      if (d == 0) {
+        rep.mttkrp_plan = cals_hip_tree(e);
+        if (p.with_time) {  // the first device's log stands for the run
+          fill_timers(e, rep);
+          cals_hip_set_sweep_log(e, 0);
+        }
       }
-      if ((rc = cals_hip_get_report(g.e, &reports[d]))) fail(g.e, "cals_hip_get_report", rc);
+      lease.done();
     } catch (...) {
       errors[d] = std::current_exception();
       next.store(all.size());  // the other devices finish what they hold and stop claiming
@@ -176,6 +288,64 @@ void cp_cals_devices(const Tensor &X, std::vector<std::reference_wrapper<Ktensor
 }
 }  // namespace
 
+void CalsParams::print() const {
+  using std::cout;
+  using std::endl;
+  cout << "---------------------------------------" << endl;
+  cout << "CALS parameters" << endl;
+  cout << "---------------------------------------" << endl;
+  cout << "Tol:             " << tol << endl;
+  cout << "Max Iterations:  " << max_iterations << endl;
+  cout << "Buffer Size:     " << buffer_size << endl;
+  cout << "Mttkrp Method:   " << mttkrp::mttkrp_method_names[mttkrp_method] << " (the device engine picks its own plan)" << endl;
+  cout << "Update Method:   " << update::update_method_names[update_method] << endl;
+  cout << "Line Search:     " << (line_search ? "true" : "false") << endl;
+  if (line_search) {
+    cout << "-Line Search Interval: " << line_search_interval << " iterations" << endl;
+    cout << "-Line Search Method:   " << ls::ls_method_names[line_search_method] << endl;
+  }
+  cout << "CUDA:            " << (cuda ? "true" : "false") << " (device path: MI355X HIP engine, device";
+  if (devices.empty())
+    cout << " " << device;
+  else
+    for (int d : devices) cout << " " << d;
+  cout << ", " << (precision == FP32 ? "fp32" : "fp64") << " storage)" << endl;
+  cout << "---------------------------------------" << endl;
+}
+
+void CalsReport::print_header(const std::string &file_name, const std::string &sep) const {
+  std::ofstream file(file_name, std::ios::out);
+  AlsTimers als_timers;
+  ModeTimers mode_timers;
+  for (const char *col : {"TENSOR_RANK", "TENSOR_MODES", "BUFFER_SIZE", "N_KTENSORS", "KTENSOR_COMP_SUM", "UPDATE_METHOD",
+                          "LINE_SEARCH", "MAX_ITERS", "ITER", "NUM_THREADS", "TOTAL"})
+    file << col << sep;
+  if (!flops_per_iteration.empty()) {
+    file << "FLOPS" << sep << "COLS" << sep;
+    for (const auto &name : als_timers.names) file << name << sep;
+    for (dim_t m = 0; m < modes.size(); m++)
+      for (const auto &name : mode_timers.names) file << "MODE_" << m << "_" << name << sep;
+  }
+  file << std::endl;
+}
+
+void CalsReport::print_to_file(const std::string &file_name, const std::string &sep) const {
+  std::ofstream file(file_name, std::ios::app);
+  const bool timed = !flops_per_iteration.empty();
+  for (dim_t it = 0; it < iter; it++) {  // one row per outer iteration
+    file << tensor_rank << sep << utils::mode_string(modes) << sep << buffer_size << sep << n_ktensors << sep
+         << ktensor_comp_sum << sep << update::update_method_names[update_method] << sep << line_search << sep
+         << max_iter << sep << it + 1 << sep << n_threads << sep << total_time << sep;
+    if (timed && it < flops_per_iteration.size()) {
+      file << flops_per_iteration[it] << sep << cols[it] << sep << std::scientific;
+      for (dim_t r = 0; r < als_times.get_rows(); r++) file << als_times(r, it) << sep;
+      for (dim_t r = 0; r < mode_times.get_rows(); r++) file << mode_times(r, it) << sep;
+      file << std::defaultfloat;
+    }
+    file << std::endl;
+  }
+}
+
 CalsReport cp_cals(const Tensor &X, KtensorQueue &kt_queue, CalsParams &p) {
   const auto t0 = std::chrono::steady_clock::now();
   if (!p.cuda)
@@ -186,6 +356,7 @@ CalsReport cp_cals(const Tensor &X, KtensorQueue &kt_queue, CalsParams &p) {
   rep.n_modes = X.get_n_modes();
   rep.modes = X.get_modes();
   rep.max_iter = p.max_iterations;
+  rep.n_threads = get_threads();
   rep.buffer_size = p.buffer_size;
   rep.tol = p.tol;
   rep.cuda = true;
@@ -205,249 +376,42 @@ CalsReport cp_cals(const Tensor &X, KtensorQueue &kt_queue, CalsParams &p) {
     rep.total_time = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     return rep;
   }
-  std::vector<int64_t> modes(X.get_modes().begin(), X.get_modes().end());
-  EngineGuard g;
-  int rc = cals_hip_create_ex(&g.e, (int)modes.size(), modes.data(), (int64_t)p.buffer_size,
-                              p.devices.size() == 1 ? p.devices[0] : p.device,
-                              p.precision == CalsParams::FP32 ? CALS_HIP_F32 : CALS_HIP_F64);
-  if (rc) fail(g.e, "cals_hip_create", rc);
-  if ((rc = cals_hip_set_tensor(g.e, X.get_data()))) fail(g.e, "cals_hip_set_tensor", rc);
+  EngineLease lease(X, (int64_t)p.buffer_size, p.devices.size() == 1 ? p.devices[0] : p.device,
+                    p.precision == CalsParams::FP32 ? CALS_HIP_F32 : CALS_HIP_F64, p.reuse_device_tensor);
+  cals_hip_engine *e = lease.get();
   cals_hip_params hp = to_hip_params(p);
-  if ((rc = cals_hip_set_params(g.e, &hp))) fail(g.e, "cals_hip_set_params", rc);
+  int rc = cals_hip_set_params(e, &hp);
+  if (rc) fail(e, "cals_hip_set_params", rc);
+  if (p.with_time) cals_hip_set_sweep_log(e, 1);
 
   std::vector<std::reference_wrapper<Ktensor>> kts;
   std::vector<int64_t> tickets;
   while (!kt_queue.empty()) {
     Ktensor &kt = kt_queue.front();
-    std::vector<double *> fptr;
-    for (auto &f : kt.get_factors()) fptr.push_back(f.get_data());
     int64_t ticket = -1;
-    rc = cals_hip_enqueue(g.e, (int64_t)kt.get_components(), fptr.data(), kt.get_lambda().data(),
-                          kt.is_jk() ? (int)kt.get_jk_mode() : -1, (int64_t)kt.get_jk_fiber(), &ticket);
-    if (rc) fail(g.e, "cals_hip_enqueue", rc);
+    enqueue_model(e, kt, &ticket);
     kts.push_back(kt);
     tickets.push_back(ticket);
     kt_queue.pop();
   }
   cals_hip_report hr;
-  if ((rc = cals_hip_run(g.e, &hr))) fail(g.e, "cals_hip_run", rc);
-  for (size_t i = 0; i < kts.size(); i++) {
-    cals_hip_model_status st;
-    if ((rc = cals_hip_model_result(g.e, tickets[i], &st))) fail(g.e, "cals_hip_model_result", rc);
-    Ktensor &kt = kts[i];
-    kt.set_iters((dim_t)st.iters);
-    kt.set_approximation_error(st.approx_error);
-    kt.set_fit(st.fit, st.old_fit);
-  }
+  if ((rc = cals_hip_run(e, &hr))) fail(e, "cals_hip_run", rc);
+  for (size_t i = 0; i < kts.size(); i++) read_back(e, kts[i], tickets[i]);
   rep.X_norm = hr.X_norm;
   rep.iter = (dim_t)hr.iter;
   rep.n_ktensors = (int)hr.n_ktensors;
   rep.ktensor_comp_sum = (int)hr.ktensor_comp_sum;
   rep.ls_performed = (dim_t)hr.ls_performed;
   rep.ls_failed = (dim_t)hr.ls_failed;
-  rep.total_time =
-      std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  rep.mttkrp_plan = cals_hip_tree(e);
+  if (p.with_time) {
+    fill_timers(e, rep);
+    cals_hip_set_sweep_log(e, 0);
+  }
+  lease.done();
+  rep.total_time = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   return rep;
 }
-
-
-// cp_als (include/als.h:190, src/als.cpp:19-289) on the device engine: one model in flight.
-AlsReport cp_als(const Tensor &X, Ktensor &ktensor, AlsParams &ap) {
-  CalsParams p;
-  p.update_method = ap.update_method;
-  p.max_iterations = ap.max_iterations;
-  p.tol = ap.tol;
-  p.cuda = ap.cuda;
-  p.buffer_size = ktensor.get_components();
-  p.line_search = ap.line_search;
-  p.line_search_interval = ap.line_search_interval;
-  p.line_search_step = ap.line_search_step;
-  p.line_search_method = ap.line_search_method;
-  p.force_max_iter = ap.force_max_iter;
-  p.device = ap.device;
-  KtensorQueue q;
-  q.emplace(ktensor);
-  CalsReport r = cp_cals(X, q, p);
-  AlsReport out;
-  out.iter = r.iter;
-  out.ls_performed = r.ls_performed;
-  out.ls_failed = r.ls_failed;
-  out.X_norm = r.X_norm;
-  out.total_time = r.total_time;
-  return out;
-}
-
-// ---------------------------------------------------------------------------------------------
-// Linear sum assignment.  The reference hands this to SciPy's rectangular_lsap
-// (extern/rectangular_lsap/rectangular_lsap.cpp: Crouse's shortest-augmenting-path variant of
-// Jonker-Volgenant).  Own implementation of the same published algorithm (D. F. Crouse, "On
-// implementing 2D rectangular assignment algorithms", IEEE T-AES 52(4), 2016), including its two
-// tie rules -- the unvisited columns are scanned from the last to the first, and among equally short
-// paths one that ends in an unassigned column wins -- so that degenerate costs (ties) give the
-// assignment the reference gives, not merely one of equal value.  tests: against oracle/_ref's build
-// of the reference's own file, scipy.optimize and exhaustive search.
-// ---------------------------------------------------------------------------------------------
-namespace {
-struct LsapSolver {
-  int64_t nr, nc;                 // nr <= nc
-  std::vector<double> c;          // row-major nr x nc, non-negative, minimisation form
-  std::vector<double> u, v, dist;
-  std::vector<int64_t> pred, col_of_row, row_of_col, todo;
-  std::vector<char> row_seen, col_seen;
-
-  LsapSolver(int64_t nr_, int64_t nc_)
-      : nr(nr_), nc(nc_), c((size_t)(nr_ * nc_)), u((size_t)nr_, 0.0), v((size_t)nc_, 0.0), dist((size_t)nc_),
-        pred((size_t)nc_, -1), col_of_row((size_t)nr_, -1), row_of_col((size_t)nc_, -1), todo((size_t)nc_),
-        row_seen((size_t)nr_), col_seen((size_t)nc_) {}
-
-  // shortest augmenting path from row `start`; returns the free column it ends in (-1: infeasible)
-  int64_t grow(int64_t start, double &reach) {
-    std::fill(row_seen.begin(), row_seen.end(), 0);
-    std::fill(col_seen.begin(), col_seen.end(), 0);
-    std::fill(dist.begin(), dist.end(), std::numeric_limits<double>::infinity());
-    int64_t n_todo = nc;
-    for (int64_t k = 0; k < nc; k++) todo[(size_t)k] = nc - 1 - k;  // last column first
-    double level = 0.0;
-    int64_t i = start;
-    for (;;) {
-      row_seen[(size_t)i] = 1;
-      int64_t pick = -1;
-      double best = std::numeric_limits<double>::infinity();
-      for (int64_t k = 0; k < n_todo; k++) {
-        const int64_t j = todo[(size_t)k];
-        const double via = level + c[(size_t)(i * nc + j)] - u[(size_t)i] - v[(size_t)j];
-        if (via < dist[(size_t)j]) {
-          dist[(size_t)j] = via;
-          pred[(size_t)j] = i;
-        }
-        if (dist[(size_t)j] < best || (dist[(size_t)j] == best && row_of_col[(size_t)j] < 0)) {
-          best = dist[(size_t)j];
-          pick = k;
-        }
-      }
-      level = best;
-      if (pick < 0 || level == std::numeric_limits<double>::infinity()) return -1;
-      const int64_t j = todo[(size_t)pick];
-      col_seen[(size_t)j] = 1;
-      todo[(size_t)pick] = todo[(size_t)(--n_todo)];
-      if (row_of_col[(size_t)j] < 0) {
-        reach = level;
-        return j;
-      }
-      i = row_of_col[(size_t)j];
-    }
-  }
-
-  int run() {
-    for (int64_t row = 0; row < nr; row++) {
-      double reach = 0.0;
-      const int64_t sink = grow(row, reach);
-      if (sink < 0) return -1;
-      u[(size_t)row] += reach;  // dual update
-      for (int64_t i = 0; i < nr; i++)
-        if (row_seen[(size_t)i] && i != row) u[(size_t)i] += reach - dist[(size_t)col_of_row[(size_t)i]];
-      for (int64_t j = 0; j < nc; j++)
-        if (col_seen[(size_t)j]) v[(size_t)j] -= reach - dist[(size_t)j];
-      for (int64_t j = sink;;) {  // flip the path
-        const int64_t i = pred[(size_t)j];
-        row_of_col[(size_t)j] = i;
-        std::swap(col_of_row[(size_t)i], j);
-        if (i == row) break;
-      }
-    }
-    return 0;
-  }
-};
-}  // namespace
-
-// n x n, column-major cost: col_of_row[i] = column assigned to row i
-int solve_linear_sum_assignment(int n, const double *cost, bool maximize, int64_t *col_of_row) {
-  if (n < 1 || !cost || !col_of_row) return -2;
-  std::vector<double> rm((size_t)n * n);
-  for (int i = 0; i < n; i++)
-    for (int j = 0; j < n; j++) rm[(size_t)i * n + j] = cost[(size_t)i + (size_t)n * j];
-  std::vector<int64_t> rows((size_t)n);
-  return ::solve_rectangular_linear_sum_assignment(n, n, rm.data(), maximize, rows.data(), col_of_row);
-}
-
-namespace utils {
-
-std::string mode_string(vector<dim_t> const &modes) {  // src/utils/utils.cpp:9-16
-  std::string m;
-  for (auto const &v : modes) m += std::to_string(v) + '-';
-  if (!m.empty()) m.pop_back();
-  return m;
-}
-
-Ktensor concatenate_ktensors(vector<Ktensor> const &ktensors) {  // src/utils/utils.cpp:18-38
-  const dim_t comp = ktensors[0].get_components();
-  Ktensor out(ktensors.size() * comp, ktensors[0].get_modes());
-  dim_t index = 0;
-  for (auto const &kt : ktensors) {
-    for (dim_t i = 0; i < comp; i++) out.get_lambda()[index * comp + i] = kt.get_lambda()[i];
-    for (dim_t m = 0; m < kt.get_n_modes(); m++)
-      for (dim_t c = 0; c < comp; c++)
-        for (dim_t r = 0; r < kt.get_factor(m).get_rows(); r++)
-          out.get_factor(m)(r, index * comp + c) = kt.get_factor(m)(r, c);
-    index++;
-  }
-  return out;
-}
-
-void generate_jk_ktensors(Ktensor const &reference_ktensor, vector<Ktensor> &jk_ktensor_v) {
-  // src/utils/utils.cpp:40-52: one copy per mode-0 slice, flagged jk(mode 0, fiber i)
-  const dim_t I0 = reference_ktensor.get_modes()[0];
-  if (I0 <= 1) throw std::string("Can't do Jack-knife with just one sample.");
-  for (dim_t i = 0; i < I0; i++) {
-    Ktensor copy(reference_ktensor);
-    copy.to_jk(0, i);
-    jk_ktensor_v.push_back(std::move(copy));
-  }
-}
-
-void jk_permutation_adjustment(Ktensor &ktensor, vector<Ktensor> &jk_ktensor_v) {
-  // src/utils/utils.cpp:54-101, restated LITERALLY including its orientation: M(i, j) =
-  // <Bov_i, Bm_j> + <Cov_i, Cm_j> (i = column of the overall model, j = column of the replica) is
-  // built COLUMN-major and handed to the assignment solver, which reads ROW-major
-  // (rectangular_lsap.cpp:93: cost[i * nc + j]).  The solver therefore works on M^T: its row r is
-  // replica column r and solved[r] is the overall column matched to it.  The reference then sets
-  // new(:, cur) = old(:, solved[cur]) -- the INVERSE of the permutation that would line the replica up
-  // with the overall model (that one is new(:, solved[r]) = old(:, r)).  The two coincide when the
-  // matching is an involution (identity, swaps: the common case, which is why the reference's own
-  // FunctionCorrectness test cannot tell); for a 3-cycle they differ.  Parity with the reference is
-  // the contract here, so the call and the copy are kept exactly as the reference has them
-  // (DESIGN.md section 5 "Reference quirks kept"; tests/test_lsap_and_jk_permutation.py pins a 3-cycle).
-  const auto &modes = ktensor.get_modes();
-  const dim_t comp = ktensor.get_components();
-  const Matrix &Bov = ktensor.get_factor(1), &Cov = ktensor.get_factor(2);
-  for (dim_t m = 0; m < modes[0]; m++) {
-    Ktensor &kt = jk_ktensor_v[m];
-    const Matrix &Bm = kt.get_factor(1), &Cm = kt.get_factor(2);
-    Matrix M(comp, comp);
-    for (dim_t j = 0; j < comp; j++)
-      for (dim_t i = 0; i < comp; i++) {
-        double s = 0.0, t = 0.0;
-        for (dim_t r = 0; r < modes[1]; r++) s += Bov(r, i) * Bm(r, j);
-        for (dim_t r = 0; r < modes[2]; r++) t += Cov(r, i) * Cm(r, j);
-        M(i, j) = s + t;
-      }
-    std::vector<int64_t> init_v(comp), solved_v(comp);
-    ::solve_rectangular_linear_sum_assignment((intptr_t)comp, (intptr_t)comp, M.get_data(), true, init_v.data(),
-                                              solved_v.data());
-    for (dim_t mode = 0; mode < ktensor.get_n_modes(); mode++) {
-      Matrix &f = kt.get_factor(mode);
-      Matrix copy(f.get_rows(), f.get_cols());
-      copy.copy(f);
-      for (dim_t cur = 0; cur < comp; cur++) {
-        const dim_t swap = (dim_t)solved_v[cur];
-        if (swap != cur)
-          for (dim_t r = 0; r < f.get_rows(); r++) f(r, cur) = copy(r, swap);
-      }
-    }
-  }
-}
-
-}  // namespace utils
 
 JKReport jk_cp_cals(const Tensor &X, vector<Ktensor> &kt_vector, CalsParams &cals_params) {
   vector<Ktensor> ktensors(kt_vector);
@@ -481,182 +445,4 @@ JKReport jk_cp_cals(const Tensor &X, vector<Ktensor> &kt_vector, CalsParams &cal
   return rep;
 }
 
-namespace {
-CalsParams to_cals_params(const AlsParams &ap, dim_t buffer_size) {
-  CalsParams p;
-  p.update_method = ap.update_method;
-  p.max_iterations = ap.max_iterations;
-  p.tol = ap.tol;
-  p.cuda = ap.cuda;
-  p.buffer_size = buffer_size;
-  p.line_search = ap.line_search;
-  p.line_search_interval = ap.line_search_interval;
-  p.line_search_step = ap.line_search_step;
-  p.line_search_method = ap.line_search_method;
-  p.force_max_iter = ap.force_max_iter;
-  p.device = ap.device;
-  return p;
-}
-}  // namespace
-
-// cp_omp_als (include/als.h:218, src/als.cpp:340-360): every model fitted independently by ALS.  The
-// reference spreads the models over OpenMP threads; on the device "all of them at once" IS the
-// concurrent engine, whose per-model results equal cp_als (tests/cals/test_cals.cpp:60-86).
-vector<AlsReport> cp_omp_als(const Tensor &X, vector<Ktensor> &ktensor_v, AlsParams &params) {
-  Timer total;
-  total.start();
-  dim_t cols = 0;
-  for (auto &k : ktensor_v) cols += k.get_components();
-  CalsParams p = to_cals_params(params, std::max<dim_t>(cols, 1));
-  KtensorQueue q;
-  for (auto &k : ktensor_v) q.emplace(k);
-  CalsReport r = cp_cals(X, q, p);
-  total.stop();
-  vector<AlsReport> reports(ktensor_v.size());
-  for (size_t i = 0; i < ktensor_v.size(); i++) {
-    reports[i].iter = ktensor_v[i].get_iters();
-    reports[i].X_norm = r.X_norm;
-    reports[i].total_time = total.get_time();
-  }
-  return reports;
-}
-
-// jk_cp_als / jk_cp_omp_als (include/als.h:203,220, src/als.cpp:362-500): the jackknife comparator --
-// every replica is a plain model of the SUB-SAMPLED tensor (mode-0 slice i removed).  Replicas of
-// all input models that share a removed slice share one engine run on that sub-tensor.
-JKReport jk_cp_omp_als(const Tensor &X, vector<Ktensor> &kt_vector, AlsParams &als_params) {
-  const auto modes = X.get_modes();
-  if (modes.size() != 3) throw std::runtime_error("jk_cp_als: 3-way tensors only (src/als.cpp:364-365)");
-  const dim_t I0 = modes[0], rest = modes[1] * modes[2];
-  vector<Ktensor> ktensors(kt_vector);
-  for (auto &k : ktensors) {
-    k.denormalize();
-    k.normalize();
-  }
-  auto jk_modes(modes);
-  jk_modes[0] -= 1;
-  vector<vector<Ktensor>> jk_input(ktensors.size());
-  for (auto &k : jk_input) k.resize(I0);
-  double pre_time = 0.0, als_time = 0.0;
-  for (dim_t i_jk = 0; i_jk < I0; i_jk++) {
-    Timer pre, run;
-    pre.start();
-    Tensor X_jk(jk_modes);
-    for (dim_t jj = 0; jj < rest; jj++)
-      for (dim_t ii = 0; ii < I0; ii++) {
-        if (ii == i_jk) continue;
-        X_jk[(ii < i_jk ? ii : ii - 1) + (I0 - 1) * jj] = X[ii + I0 * jj];
-      }
-    dim_t cols = 0;
-    for (size_t i_kt = 0; i_kt < ktensors.size(); i_kt++) {
-      const Ktensor &src = ktensors[i_kt];
-      Ktensor kt_jk(src.get_components(), jk_modes);
-      kt_jk.get_lambda() = src.get_lambda();
-      for (dim_t f = 0; f < 3; f++) {
-        const Matrix &fs = src.get_factor(f);
-        Matrix &fd = kt_jk.get_factor(f);
-        for (dim_t jj = 0; jj < fs.get_cols(); jj++)
-          for (dim_t ii = 0; ii < fs.get_rows(); ii++) {
-            if (f == 0 && ii == i_jk) continue;
-            fd((f == 0 && ii > i_jk) ? ii - 1 : ii, jj) = fs(ii, jj);
-          }
-      }
-      cols += src.get_components();
-      jk_input[i_kt][i_jk] = std::move(kt_jk);
-    }
-    pre.stop();
-    run.start();
-    CalsParams p = to_cals_params(als_params, std::max<dim_t>(cols, 1));
-    KtensorQueue q;
-    for (size_t i_kt = 0; i_kt < ktensors.size(); i_kt++) q.emplace(jk_input[i_kt][i_jk]);
-    cp_cals(X_jk, q, p);
-    run.stop();
-    pre_time += pre.get_time();
-    als_time += run.get_time();
-  }
-  for (auto &k : jk_input)
-    for (auto &m : k) {
-      m.denormalize();
-      m.normalize();
-    }
-  for (size_t i = 0; i < ktensors.size(); i++) utils::jk_permutation_adjustment(ktensors[i], jk_input[i]);
-  JKReport rep;
-  rep.jk_time.pre_als_time = pre_time;
-  rep.jk_time.als_time = als_time;
-  rep.results = std::move(jk_input);
-  return rep;
-}
-
-JKReport jk_cp_als(const Tensor &X, vector<Ktensor> &kt_vector, AlsParams &als_params) {
-  return jk_cp_omp_als(X, kt_vector, als_params);
-}
-
 }  // namespace cals
-
-// extern/rectangular_lsap/rectangular_lsap.h:44, same contract: row-major nr x nc cost; on return
-// (a[k], b[k]), k < min(nr, nc), are the assigned (row, column) pairs sorted by row.  Returns 0,
-// -1 (infeasible) or -2 (NaN / -inf entry), the reference's RECTANGULAR_LSAP_* codes.
-extern "C" int solve_rectangular_linear_sum_assignment(intptr_t nr, intptr_t nc, double *input_cost,
-                                                        bool maximize, int64_t *a, int64_t *b) {
-  if (nr == 0 || nc == 0) return 0;
-  if (nr < 0 || nc < 0 || !input_cost || !a || !b) return -2;
-  const bool tall = nc < nr;  // the solver wants rows <= columns: work on the transpose
-  const int64_t R = tall ? nc : nr, Cn = tall ? nr : nc;
-  cals::LsapSolver sv(R, Cn);
-  for (int64_t i = 0; i < nr; i++)
-    for (int64_t j = 0; j < nc; j++) {
-      const double x = input_cost[(size_t)(i * nc + j)];
-      sv.c[(size_t)(tall ? j * nr + i : i * nc + j)] = maximize ? -x : x;
-    }
-  double lo = sv.c[0];
-  for (double x : sv.c) lo = (x < lo) ? x : lo;
-  for (double &x : sv.c) {
-    x -= lo;  // non-negative costs
-    if (x != x || x == -std::numeric_limits<double>::infinity()) return -2;
-  }
-  if (sv.run()) return -1;
-  if (!tall) {
-    for (int64_t i = 0; i < nr; i++) {
-      a[i] = i;
-      b[i] = sv.col_of_row[(size_t)i];
-    }
-  } else {  // solver rows are the caller's columns: list the pairs by the caller's row
-    std::vector<int64_t> order((size_t)R);
-    for (int64_t k = 0; k < R; k++) order[(size_t)k] = k;
-    std::sort(order.begin(), order.end(),
-              [&](int64_t x, int64_t y) { return sv.col_of_row[(size_t)x] < sv.col_of_row[(size_t)y]; });
-    for (int64_t k = 0; k < R; k++) {
-      a[k] = sv.col_of_row[(size_t)order[(size_t)k]];
-      b[k] = order[(size_t)k];
-    }
-  }
-  return 0;
-}
-
-// C entry point of the assignment solver (tests bind it with ctypes)
-extern "C" int cals_lsap_solve(int n, const double *cost_colmajor, int maximize, int64_t *col_of_row) {
-  return cals::solve_linear_sum_assignment(n, cost_colmajor, maximize != 0, col_of_row);
-}
-
-// C entry point of utils::jk_permutation_adjustment (tests bind it with ctypes): `overall` = the n_modes
-// factors of the overall model, `replicas` = modes[0] * n_modes factor pointers, replica-major; the
-// replicas' columns are reordered in place.
-extern "C" int cals_jk_permutation_adjustment(int n_modes, const int64_t *modes, int64_t rank,
-                                               const double *const *overall, double *const *replicas) {
-  if (n_modes < 3 || !modes || rank < 1 || !overall || !replicas) return -1;
-  std::vector<dim_t> md(modes, modes + n_modes);
-  cals::Ktensor ov((dim_t)rank, md);
-  for (int n = 0; n < n_modes; n++) ov.set_factor(n, overall[n]);
-  std::vector<cals::Ktensor> reps;
-  for (dim_t m = 0; m < md[0]; m++) {
-    reps.emplace_back((dim_t)rank, md);
-    for (int n = 0; n < n_modes; n++) reps.back().set_factor(n, replicas[m * n_modes + n]);
-  }
-  cals::utils::jk_permutation_adjustment(ov, reps);
-  for (dim_t m = 0; m < md[0]; m++)
-    for (int n = 0; n < n_modes; n++) {
-      const cals::Matrix &f = reps[m].get_factor((dim_t)n);
-      std::copy(f.get_data(), f.get_data() + f.get_n_elements(), replicas[m * n_modes + n]);
-    }
-  return 0;
-}

@@ -8,7 +8,8 @@
 #include <string>
 #include <vector>
 
-#include "../cals/cals.h"
+#include "als.h"
+#include "cals.h"
 #include "crash_trace.h"
 
 using std::cerr;

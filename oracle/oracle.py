@@ -59,7 +59,8 @@ def build(force=False):
 def lib():
     global _LIB
     if _LIB is None:
-        _LIB = C.CDLL(build())
+        # CALS_ORACLE_LIB: another build of the same source (tests load the ASan/UBSan one)
+        _LIB = C.CDLL(os.environ.get("CALS_ORACLE_LIB") or build())
         _LIB.or_norm.restype = C.c_double
         _LIB.or_fast_error.restype = C.c_double
         # parity runs are single-threaded and deterministic; the cpu_baseline leg raises this.

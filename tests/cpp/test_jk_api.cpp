@@ -6,7 +6,8 @@
 #include <cstring>
 #include <vector>
 
-#include "../../cp-cals_amd/cals/cals.h"
+#include "als.h"
+#include "cals.h"
 #include "../../oracle/cals_oracle.h"
 
 static uint64_t g_state = 12345;
