@@ -66,7 +66,12 @@ struct TreePlan {
   void *Pt = nullptr;    // packed factor of mode a: [NB][Ap][CALS_BN]
   int t_second = -1;     // T currently holds the TTM whose `second` is this mode (-1: none) ...
   int t_first = -1;      // ... computed as pair[t_first]
-  int *d_changed = nullptr;  // set by ls_kernel when a line-search step rewrote factors
+  int *d_changed = nullptr;  // ls_kernel adds the rank of every model whose factors it rewrote
+  // T[:, :, c] depends on column c of factor a only: a line-search step that rewrites some models leaves
+  // the other models' columns of a pending T valid.  n_stale > 0: that many columns (listed in
+  // d_stale_idx at the time they are needed) must be recomputed when the pending T is consumed.
+  int n_stale = 0;
+  int *d_stale_idx = nullptr;
 };
 
 struct EventPair {
@@ -631,7 +636,68 @@ int launch_contract(cals_hip_engine *e, int64_t R, void *out) {
   return CALS_HIP_OK;
 }
 
-void tree_invalidate(cals_hip_engine *e) { e->tree.t_second = e->tree.t_first = -1; }
+void tree_invalidate(cals_hip_engine *e) {
+  e->tree.t_second = e->tree.t_first = -1;
+  e->tree.n_stale = 0;
+}
+
+// A line-search step rewrote `changed` columns (0: none) while a T is pending across the sweep boundary.
+// Few of them: keep T, the consumer recomputes just those columns (patch_stale_columns).  Many (the
+// sweeps in which every model extrapolates), or an error-checking line search: T is dropped and the next
+// mode runs a fresh TTM -- which costs about what patching more than half of the columns would, and
+// leaves a T for the mode after it.
+void note_ls_changes(cals_hip_engine *e, int changed) {
+  if (changed <= 0 || e->tree.t_second < 0) return;
+  const char *env = getenv("CALS_TREE_PATCH_MAX");  // tests: 0 = always drop, 1 = always patch
+  const double keep_below = env ? atof(env) : 0.5;
+  if (e->prm.line_search_method == 0 && (double)changed <= keep_below * (double)e->end)
+    e->tree.n_stale = changed;
+  else
+    tree_invalidate(e);
+}
+
+int ensure_col_scratch(cals_hip_engine *e, size_t words, size_t n_idx);
+
+// G[:, c] of mode n (just written by the contraction of the pending T) is wrong for the n_stale columns
+// whose a-mode factor a line-search step rewrote after T was formed: gather those columns of the two
+// other factors into packed copies, run the fused MTTKRP on them, scatter the result over G.
+int patch_stale_columns(cals_hip_engine *e, int n) {
+  TreePlan &tp = e->tree;
+  const ModeLayout &L = e->lay[n];
+  const int ns = (int)e->registry.size(), nc = tp.n_stale;
+  const int am = L.a_mode, sm = L.s_modes[0];
+  const int wpe = (e->dtype == CALS_F32) ? 1 : 2;
+  const int pk0 = prof_begin(e, 2, 0, LOG_FUSED);
+  HIPCHK(stale_cols_launch(e->d_slots, ns, e->mt, tp.d_stale_idx, e->stream));
+  ColMoveArgs a{};
+  a.buf[0] = ColBuf{e->factor[am], (long long)e->modes[am], wpe};
+  a.buf[1] = ColBuf{e->factor[sm], (long long)e->modes[sm], wpe};
+  a.n_bufs = 2;
+  a.scratch_off[0] = 0;
+  // whole 128-column blocks: the MTTKRP reads (and ignores) the columns that pad the last block
+  const size_t padded = (size_t)((nc + CALS_BN - 1) / CALS_BN) * CALS_BN;
+  a.scratch_off[1] = (long long)((size_t)e->modes[am] * wpe * padded);
+  const size_t words = (size_t)(e->modes[am] + e->modes[sm]) * wpe * padded;
+  int rc = ensure_col_scratch(e, words, 0);
+  if (rc) return rc;
+  a.src = tp.d_stale_idx;
+  a.dst = tp.d_stale_idx;
+  a.n_cols = nc;
+  a.scratch = e->col_scratch;
+  a.zero_src_bufs = 0;
+  HIPCHK(gather_columns_launch(a, e->stream));
+  prof_end(e, pk0);
+  void *fset[CALS_HIP_MAX_MODES] = {nullptr};
+  fset[am] = e->col_scratch + a.scratch_off[0];
+  fset[sm] = e->col_scratch + a.scratch_off[1];
+  Geo g{0, 0};
+  if ((rc = launch_mttkrp(e, n, nc, &g, fset))) return rc;
+  const int pk1 = prof_begin(e, 2, 0, LOG_FUSED);
+  HIPCHK(reduce_partials_scatter_launch(e->partial, g.T, L.ldPart, (int)e->modes[n], nc, e->factor[n],
+                                        tp.d_stale_idx, e->dtype, e->stream));
+  prof_end(e, pk1);
+  return CALS_HIP_OK;
+}
 
 LsArgs make_ls_args(cals_hip_engine *e) {
   LsArgs a{};
@@ -694,6 +760,7 @@ int sweep_once(cals_hip_engine *e, bool evict_enabled, bool defer_changed = fals
     const bool by_contract = e->tree.on && e->tree.t_second == n;
     if (by_contract) {
       if ((rc = launch_contract(e, R, e->factor[n]))) return rc;
+      if (e->tree.n_stale > 0 && (rc = patch_stale_columns(e, n))) return rc;
       tree_invalidate(e);  // T is consumed: mode a of the pair is updated next
     } else if (e->tree.on && e->tree.pair[n].on &&
                !(e->tree.kind == 3 && n == e->n_modes - 1 && evict_enabled && !e->queue.empty())) {
@@ -791,7 +858,7 @@ int sweep_once(cals_hip_engine *e, bool evict_enabled, bool defer_changed = fals
       HIPCHK(hipMemcpyAsync(&changed, e->tree.d_changed, sizeof(int), hipMemcpyDeviceToHost,
                             e->stream));
       HIPCHK(hipStreamSynchronize(e->stream));
-      if (changed) tree_invalidate(e);
+      note_ls_changes(e, changed);
     }
   }
   if (!e->prm.always_evict_first || !evict_enabled) {
@@ -834,7 +901,7 @@ int fetch_status(cals_hip_engine *e) {
   HIPCHK(hipStreamSynchronize(e->stream));
   e->arena_off = 0;  // the stream is idle: every staged copy has been consumed
   if (e->changed_deferred) {
-    if (e->h_status[0].flags) tree_invalidate(e);
+    note_ls_changes(e, e->h_status[0].flags);
     e->changed_deferred = false;
   }
   e->nnls_status |= e->h_status[0].pad;
@@ -1377,6 +1444,7 @@ int cals_hip_create_ex(cals_hip_engine **out, int n_modes, const int64_t *modes,
   if ((rc = dev_alloc(e, &e->lambda, (size_t)buffer_size))) return rc;
   const size_t nb_max = (size_t)((buffer_size + CALS_BN - 1) / CALS_BN);
   if ((rc = dev_alloc(e, &e->tree.d_changed, (size_t)1))) return rc;
+  if ((rc = dev_alloc(e, &e->tree.d_stale_idx, (size_t)buffer_size))) return rc;
   if (e->tree.on) {
     TreePlan &tp = e->tree;
     size_t t_elems = 0, pt_elems = 0;
@@ -1545,6 +1613,7 @@ int cals_hip_destroy(cals_hip_engine *e) {
   fr(e->tree.Tbuf);
   fr(e->tree.Pt);
   fr(e->tree.d_changed);
+  fr(e->tree.d_stale_idx);
   fr(e->d_status);
   if (e->h_status) (void)hipHostFree(e->h_status);
   fr(e->dbg_trace);

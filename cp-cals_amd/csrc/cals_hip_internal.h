@@ -182,6 +182,11 @@ hipError_t nnls_reset_launch(const int *desc, int n, const NnlsResetArgs &a, hip
 // deterministic reduction of the MTTKRP split partials into the multi-factor of the mode
 hipError_t reduce_partials_launch(const void *partial, int T, int ldPart, int I, int R,
                                   void *factor, int dtype, hipStream_t st);
+// the same reduction for a compact column set: column k of the tiles -> column idx[k] of the factor
+hipError_t reduce_partials_scatter_launch(const void *partial, int T, int ldPart, int I, int n_cols,
+                                          void *factor, const int *idx, int dtype, hipStream_t st);
+// idx[0 .. count) = columns of the models the last ls_kernel rewrote (mt.flags & 3), registry order
+hipError_t stale_cols_launch(const int *slots, int n, const ModelTable &mt, int *idx, hipStream_t st);
 // desc: n x {slot, col, rank, jk_mode, jk_fiber}
 hipError_t init_slots_launch(const int *desc, int n, const ModelTable &mt, hipStream_t st);
 
@@ -214,7 +219,8 @@ struct LsArgs {
   int interval;
   double step;            // 0 => cbrt(iters)
   long long max_iter;
-  int *changed;           // ls_kernel: set to 1 when any model's factors were rewritten (may be null)
+  int *changed;           // ls_kernel: += rank of every model whose factors it rewrote (may be null);
+                          // the error-checking kernels set it to 1
   // ERROR_CHECKING line search (ls_ec_*): MTTKRP of mode 0 with the extrapolated factors, I[0] x R
   const void *Gs;
   double X_norm;

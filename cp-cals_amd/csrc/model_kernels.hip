@@ -1038,6 +1038,76 @@ hipError_t reduce_partials_launch(const void *partial, int T, int ldPart, int I,
   return hipGetLastError();
 }
 
+// Same reduction for a COMPACT set of columns: column k of the partial tiles goes to column idx[k] of
+// the multi-factor (the stale columns of a dimension-tree T that a line-search step rewrote are
+// recomputed by the fused MTTKRP on a packed copy of just those columns).
+template <typename E>
+__global__ void __launch_bounds__(256) reduce_partials_scatter_kernel(const E *partial, int T, int ldPart,
+                                                                      int I, E *factor, const int *idx) {
+  const int c = blockIdx.y;
+  const long long tile = (long long)ldPart * CALS_BN;
+  const E *base = partial + (long long)(c >> 7) * T * tile + (long long)ldPart * (c & (CALS_BN - 1));
+  E *dst = factor + (long long)I * idx[c];
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < I; i += gridDim.x * blockDim.x) {
+    const E *p = base + i;
+    double s = 0.0;
+    for (int t = 0; t < T; ++t) s += (double)p[t * tile];
+    dst[i] = (E)s;
+  }
+}
+
+hipError_t reduce_partials_scatter_launch(const void *partial, int T, int ldPart, int I, int n_cols,
+                                          void *factor, const int *idx, int dtype, hipStream_t st) {
+  if (n_cols <= 0) return hipSuccess;
+  const dim3 grid((I + 255) / 256, n_cols), block(256);
+  if (dtype == CALS_F32)
+    hipLaunchKernelGGL(reduce_partials_scatter_kernel<float>, grid, block, 0, st, (const float *)partial, T,
+                       ldPart, I, (float *)factor, idx);
+  else
+    hipLaunchKernelGGL(reduce_partials_scatter_kernel<double>, grid, block, 0, st, (const double *)partial,
+                       T, ldPart, I, (double *)factor, idx);
+  return hipGetLastError();
+}
+
+// Columns of the models whose factors the last line-search kernel rewrote (flags bit 0 = extrapolated,
+// bit 1 = reverted), in registry order: idx[0 .. count).  One workgroup; an exclusive scan of the ranks.
+__global__ void __launch_bounds__(256) stale_cols_kernel(const int *slots, int n, ModelTable mt, int *idx) {
+  __shared__ int sh[256];
+  __shared__ int base;
+  if (threadIdx.x == 0) base = 0;
+  __syncthreads();
+  for (int k0 = 0; k0 < n; k0 += 256) {
+    const int k = k0 + threadIdx.x;
+    int slot = -1, r = 0;
+    if (k < n) {
+      slot = slots[k];
+      if (mt.flags[slot] & 3) r = mt.rank[slot];
+    }
+    sh[threadIdx.x] = r;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {  // inclusive scan
+      const int v = (threadIdx.x >= d) ? sh[threadIdx.x - d] : 0;
+      __syncthreads();
+      sh[threadIdx.x] += v;
+      __syncthreads();
+    }
+    const int off = base + sh[threadIdx.x] - r;
+    if (r) {
+      const int col = mt.col[slot];
+      for (int c = 0; c < r; ++c) idx[off + c] = col + c;
+    }
+    __syncthreads();
+    if (threadIdx.x == 255) base += sh[255];
+    __syncthreads();
+  }
+}
+
+hipError_t stale_cols_launch(const int *slots, int n, const ModelTable &mt, int *idx, hipStream_t st) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(stale_cols_kernel, dim3(1), dim3(256), 0, st, slots, n, mt, idx);
+  return hipGetLastError();
+}
+
 // per-slot scalars of freshly admitted models (MultiKtensor::add: iters = 1, fresh LS state)
 __global__ void init_slots_kernel(const int *desc, int n, ModelTable mt) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1255,7 +1325,7 @@ __global__ void __launch_bounds__(256) ls_kernel(const LsArgs a) {
   if (tid == 0) {
     a.mt.ls_iter[slot] = ls_iter;
     a.mt.flags[slot] = flags;
-    if (flags && a.changed) atomicOr(a.changed, 1);
+    if (flags && a.changed) atomicAdd(a.changed, r);  // number of columns this line search rewrote
   }
   (void)s_lam;
 }

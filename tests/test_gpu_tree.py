@@ -108,6 +108,61 @@ def test_tree_line_search_vs_oracle(cc, oracle, inputs, plan):
     _assert_models_match(gm, om, ro.X_norm ** 2)
 
 
+@pytest.mark.parametrize("patch_max", ["1.0", "0.5", "0"])
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_plan_m_keeps_a_pending_T_across_line_search(cc, oracle, inputs, patch_max, dtype):
+    """T[:, :, c] depends on column c of one factor only.  When a line-search step rewrites some models
+    while a T is pending across the sweep boundary, the engine keeps T and recomputes just those columns
+    (gather -> fused MTTKRP on the packed columns -> scatter).  CALS_TREE_PATCH_MAX: 1.0 = always patch
+    (also when every model extrapolated), 0 = always drop T (round-1 behaviour), 0.5 = the default rule.
+    All three must give the oracle's models; with patching on, the fused MTTKRP kernel must actually have
+    run (under plan M with no queue it runs for nothing else)."""
+    modes = [36, 28, 24]
+    ranks = inputs.ranks_1_to_20(23) + [7, 3]      # R = 233: two column blocks, the second partly filled
+    X = inputs.low_rank_tensor(modes, 5, seed=13)[0] + 0.3 * inputs.tensor(modes, 9)
+    iters = 23
+    old = {k: os.environ.get(k) for k in ("CALS_HIP_TREE", "CALS_TREE_PATCH_MAX")}
+    os.environ["CALS_HIP_TREE"] = "M"
+    os.environ["CALS_TREE_PATCH_MAX"] = patch_max
+    try:
+        base = make_models(inputs, modes, ranks, seed=2)
+        e = cc.Engine(modes, sum(ranks), dtype=dtype)
+        assert e.tree == 3
+        e.set_tensor(X)
+        e.set_params(cc.default_params(max_iterations=iters, force_max_iter=1, line_search=1, line_search_interval=3))
+        gm = [cc.Model([f.copy() for f in fs], lam.copy()) for fs, lam, _ in base]
+        for m in gm:
+            e.enqueue(m)
+        e.set_profiling(1)
+        # stepwise (cals_hip_sweep: the 4-byte read-back path) for the first half, cals_hip_run after
+        assert e.admit() == len(ranks)
+        e.sweep(11)
+        ks_mid = e.kernel_stats()
+        rep = e.run()
+        ks = e.kernel_stats()
+        e.close()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    om = [oracle.Model([f.copy() for f in fs], lam.copy()) for fs, lam, _ in base]
+    ro = oracle.cp_cals(X, modes, om, oracle.default_params(
+        max_iterations=iters, force_max_iter=1, buffer_size=sum(ranks), mttkrp_method=oracle.MTTKRP,
+        line_search=1, line_search_interval=3))
+    assert ro.ls_failed > 0 and ro.ls_performed > ro.ls_failed
+    tol = 1e-8 if dtype == "f64" else 2e-3
+    for a, b in zip(gm, om):
+        assert a.iters == b.iters
+        for fa, fb in zip(a.factors, b.factors):
+            assert rel(fa, fb) < tol
+    if patch_max == "0":
+        assert ks.mttkrp_launches == 0
+    else:
+        assert ks_mid.mttkrp_launches > 0 and ks.mttkrp_launches > ks_mid.mttkrp_launches
+
+
 def test_tree_error_checking_line_search_vs_oracle(cc, oracle, inputs, plan):
     """An accepted ERROR_CHECKING step rewrites a model's factors: a T pending across the sweep
     boundary has to be dropped exactly as for the other method."""
