@@ -5,14 +5,14 @@
 # usage: tools/profile_round.sh <workload> [steps]
 set -e
 W=${1:-c3}
-K=${2:-20}
+K=${2:-50}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_$W
 rm -rf $OUT && mkdir -p $OUT
-rocprofv3 --kernel-trace --stats -d $OUT/kt -o $W --output-format csv -- python3 bench.py --workload $W --steps $K --warmup 5 --no-cpu-baseline > $OUT/bench_kt.log 2>&1
+rocprofv3 --kernel-trace --stats -d $OUT/kt -o $W --output-format csv -- python3 bench.py --workload $W --steps $K --warmup 5 --steady-steps 0 --no-cpu-baseline > $OUT/bench_kt.log 2>&1
 python3 tools/rocprof_summary.py $OUT/kt "bench.py ($W), rocprofv3 --kernel-trace --stats" > gpurun_out/prof_${W}_kernel_trace_stats.txt
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C -d $OUT/$C -o $W --output-format csv -- python3 bench.py --workload $W --steps $K --warmup 5 --no-cpu-baseline > $OUT/bench_$C.log 2>&1
+  rocprofv3 --pmc $C -d $OUT/$C -o $W --output-format csv -- python3 bench.py --workload $W --steps $K --warmup 5 --steady-steps 0 --no-cpu-baseline > $OUT/bench_$C.log 2>&1
   python3 tools/rocprof_summary.py $OUT/$C "bench.py ($W), rocprofv3 --pmc $C (KiB)" > gpurun_out/prof_${W}_pmc_$C.txt
 done
 tail -1 $OUT/bench_kt.log | cut -c1-300
