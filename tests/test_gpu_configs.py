@@ -1,4 +1,7 @@
-"""BASELINE.json configs 3 and 5 exercised AS CONFIGURED, through the C ABI (cals_hip_run):
+"""BASELINE.json configs 2, 3 and 5 exercised AS CONFIGURED, through the C ABI (cals_hip_run)
+(config 1 = __graft_entry__.smoke() and tests/golden/c1_20cube.npz; config 4 = tests/test_gpu_fp32.py):
+
+  C2  100^3 fp64, 64 models, line search off, 50 forced sweeps, against the oracle.
 
   C3  300^3 fp64, 256 models of rank 1 + (m mod 20) (R = 2656), line search NO_ERROR_CHECKING
       interval 5 step cbrt(iter), plan M (multi-sweep dimension tree) -- exactly what bench.py times --
@@ -60,6 +63,36 @@ def _compare(gm, om, tol=TOL_RUN):
         assert abs(g.fit - o.fit) <= 1e-10
     assert worst < tol, worst
     return worst
+
+
+def test_c2_as_configured_vs_oracle(cc, oracle, inputs):
+    """BASELINE config 2: 100^3 fp64, 64 models of rank 1 + (m mod 20) (R = 640), line search off,
+    50 forced sweeps through cals_hip_run, against the oracle."""
+    modes, iters = [100, 100, 100], 50
+    ranks = inputs.ranks_1_to_20(64)
+    X = inputs.tensor(modes, 0)
+    base = inputs.model_factors(modes, ranks, 1)
+    e = cc.Engine(modes, sum(ranks))
+    e.set_tensor(X)
+    e.set_params(cc.default_params(max_iterations=iters, force_max_iter=1))
+    gm = [cc.Model([f.copy() for f in fs], lam.copy()) for fs, lam in base]
+    for m in gm:
+        e.enqueue(m)
+    rep = e.run()
+    e.close()
+    assert rep.iter == iters and rep.ktensor_comp_sum == 640
+    th = _threads()
+    oracle.use_mkl(th)
+    oracle.set_threads(th)
+    try:
+        om = [oracle.Model([f.copy() for f in fs], lam.copy()) for fs, lam in base]
+        orep = oracle.cp_cals(X, modes, om, oracle.default_params(
+            max_iterations=iters, force_max_iter=1, buffer_size=sum(ranks), mttkrp_method=oracle.MTTKRP, threads=th))
+    finally:
+        oracle.use_own_gemm()
+        oracle.set_threads(1)
+    assert orep.iter == iters
+    _compare(gm, om)
 
 
 def test_c3_as_benched_vs_oracle(cc, oracle, inputs):
