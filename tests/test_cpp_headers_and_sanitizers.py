@@ -7,6 +7,7 @@
     the reference's driver, MEX glue and experiment CSV writers -- compiles (it RUNS in the -m gpu suite);
   * tests/cpp/test_host_api: value classes, MultiKtensor packing, tensor file reader, jackknife helpers,
     report writers -- plain and under AddressSanitizer + UBSan (SURVEY.md section 5);
+  * the engine's host side (cals_hip_engine.cpp) + the C++ layer under ASan/UBSan on a fake device;
   * the oracle's own suite re-run on an ASan/UBSan build of oracle/cals_oracle.c.
 """
 import os
@@ -69,6 +70,20 @@ def test_host_api_under_asan_ubsan(tmp_path):
              {"ASAN_OPTIONS": "detect_leaks=1:abort_on_error=0", "UBSAN_OPTIONS": "print_stacktrace=1:halt_on_error=1"})
     assert r.returncode == 0 and "all checks passed" in r.stdout, r.stderr[-4000:]
     assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr
+
+
+def test_engine_host_side_under_asan_ubsan_on_a_fake_device():
+    """cals_hip_engine.cpp's host logic + the C++ layer, life cycles with queueing / eviction / compress /
+    rebind / two engines / the CLI driver's call pattern, under ASan + UBSan + LeakSanitizer on the fake
+    device of tests/asan/fake_device.cpp (numeric kernels are no-ops there, so every model must come back
+    bit-identical)."""
+    exe = os.path.join(ROOT, "tests", "asan", "test_engine_host_asan")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=900, env=env)
+    print(r.stdout[-2000:], r.stderr[-6000:])
+    assert r.returncode == 0 and "all checks passed" in r.stdout, r.stderr[-4000:]
+    assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr and "LeakSanitizer" not in r.stderr
 
 
 ORACLE_UNDER_ASAN = r"""
