@@ -44,6 +44,42 @@ def test_reference_driver_compiles_and_links_unmodified(tmp_path):
     assert r.returncode == 1 and "MIN:MAX:COPIES" in r.stderr
 
 
+REF = "/root/reference"
+
+
+@pytest.mark.skipif(not os.path.exists(REF_DRIVER), reason="the reference tree is not present on this machine")
+@pytest.mark.parametrize("main_src", ["experiments.cpp", "experiments_jk.cpp", "experiments_letter.cpp"])
+@pytest.mark.parametrize("with_time", [0, 1])
+def test_reference_experiment_harness_compiles_and_links_unmodified(tmp_path, main_src, with_time):
+    """The reference's paper-experiment programs (src/experiments/experiments{,_jk,_letter}.cpp +
+    experiments_utils.cpp: compare_als_cals, run_cals / run_als / run_omp_als / run_jk_*, report CSVs with
+    the WITH_TIME timer matrices) against this header set and libcals.so, unmodified.  The one reference
+    header they need beyond the boundary's is their own include/experiments/experiments_utils.h, found through
+    a trailing -I of the reference's include/ (every boundary header resolves to cp-cals_amd/cals/ first)."""
+    exe = str(tmp_path / "prog")
+    srcs = [os.path.join(REF, "src", "experiments", main_src), os.path.join(REF, "src", "experiments", "experiments_utils.cpp")]
+    cmd = ["g++", "-std=c++17", "-O0", "-fopenmp", '-DSOURCE_DIR="/tmp"', "-DWITH_TIME=%d" % with_time] + INC + [
+        "-I" + os.path.join(REF, "include")] + srcs + ["-o", exe, "-L" + os.path.join(ROOT, "cp-cals_amd"), "-lcals",
+                                                       "-lcals_hip", "-Wl,-rpath," + os.path.join(ROOT, "cp-cals_amd")]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    # every header of the boundary came from this repo, not from the reference tree
+    deps = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-fopenmp", "-H", '-DSOURCE_DIR="/tmp"'] + INC + [
+        "-I" + os.path.join(REF, "include"), srcs[1]], capture_output=True, text=True, timeout=300).stderr
+    used = [ln.split()[-1] for ln in deps.splitlines() if ln.startswith(".") and "/root/reference" in ln]
+    assert used and all(u.endswith("experiments/experiments_utils.h") for u in used), used
+
+
+@pytest.mark.skipif(not os.path.exists(REF_DRIVER), reason="the reference tree is not present on this machine")
+def test_reference_mex_argument_parser_compiles_unmodified():
+    """matlab/matlab_parsing.cpp (the string-argument parser of the three MEX entry points: update-method,
+    mttkrp-method, maxiters, buffer-size, tol, cuda / no-cuda, ls / no-ls, ls-interval, ls-step on CalsParams)
+    needs no MATLAB header: it compiles against this header set as it is."""
+    r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-Wall"] + INC + ["-I" + os.path.join(REF, "matlab"),
+                       os.path.join(REF, "matlab", "matlab_parsing.cpp")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+
+
 def test_reference_style_caller_compiles():
     src = os.path.join(ROOT, "tests", "cpp", "ref_style_caller.cpp")
     r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-Wall"] + INC + [src], capture_output=True, text=True,
