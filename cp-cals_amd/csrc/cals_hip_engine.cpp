@@ -217,7 +217,13 @@ int round_up(int v, int m) { return (v + m - 1) / m * m; }
 // runtime is still whole, and nothing of ours (a kernel tail, a pinned-memory copy, an event) can be in
 // flight on the runtime's helper threads when its globals go away.
 std::atomic<unsigned long long> g_devices_used{0};
+std::atomic<bool> g_process_exiting{false};
 void drain_devices_at_exit() {
+  // From here on the runtime may be gone at any moment: an engine destroyed later (an object with static
+  // storage that owns one, e.g. a static cals::Tensor with its device mirror, whose destructor runs after
+  // the runtime's own exit handlers) must not call into HIP any more -- cals_hip_destroy then only releases
+  // its host side; the device memory goes with the process.
+  g_process_exiting.store(true);
   const unsigned long long used = g_devices_used.load();
   for (int d = 0; d < 64; d++)
     if (used & (1ull << d)) {
@@ -1581,6 +1587,10 @@ int64_t cals_hip_get_sweep_log(cals_hip_engine *e, cals_hip_sweep_record *out, i
 
 int cals_hip_destroy(cals_hip_engine *e) {
   if (!e) return CALS_HIP_OK;
+  if (g_process_exiting.load()) {  // see drain_devices_at_exit
+    delete e;
+    return CALS_HIP_OK;
+  }
   // Everything is released whatever a HIP call returns on the way (an engine whose create failed
   // half-way, or whose device is gone, must not leak the rest or its host side).
   (void)hipSetDevice(e->device);  // a process may hold engines on several GPUs

@@ -29,6 +29,17 @@ def test_reference_style_caller_runs(tmp_path):
     assert [int(ln.split(";")[8]) for ln in lines[1:]] == list(range(1, len(lines)))   # ITER column
 
 
+def test_static_tensor_with_device_mirror_exits_cleanly():
+    """The mirror's engine is destroyed during static destruction, after the HIP runtime's exit handlers:
+    cals_hip_destroy must then leave HIP alone (drain_devices_at_exit sets the flag)."""
+    exe = os.path.join(ROOT, "tests", "cpp", "static_tensor_exit")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    print(r.stdout, r.stderr[-3000:])
+    assert "fitted 4 models; mirror alive: 1" in r.stdout
+    assert r.returncode == 0, r.stderr[-3000:]
+
+
 def _models(cc, inputs, modes, ranks, seed):
     return [cc.Model([f.copy() for f in fs], lam.copy()) for fs, lam in inputs.model_factors(modes, ranks, seed)]
 
