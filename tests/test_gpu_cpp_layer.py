@@ -107,8 +107,8 @@ def test_sweep_log_feeds_the_report_matrices(cc, inputs):
     total = float(np.prod(modes))
     for k, rec in enumerate(log):
         assert rec.cols == R and rec.models == 30
-        launches = rec.flops / (2.0 * total * R)
-        assert abs(launches - round(launches)) < 1e-9 and 1 <= round(launches) <= 3     # MFMA kernels of the sweep
+        launches = rec.flops / (2.0 * total * R)   # MFMA kernels of the sweep (+ a fraction when stale
+        assert 1 - 1e-9 <= launches <= 3 + 1e-9     # columns of a pending T were patched)
         assert rec.iteration_ms > 0 and rec.defrag_ms >= 0 and rec.ls_ms > 0
         dev = sum(rec.mttkrp_ms[n] + rec.update_ms[n] for n in range(3)) + rec.ls_ms
         assert 0 < dev <= rec.iteration_ms * 1.05
