@@ -12,7 +12,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcals_hip.so")
 MAX_MODES = 8
-MAX_RANK = 64
+MAX_RANK = 256
 
 OK, ERR_ARG, ERR_HIP, ERR_STATE, ERR_FULL, ERR_NO_DEVICE = 0, 1, 2, 3, 4, 5
 

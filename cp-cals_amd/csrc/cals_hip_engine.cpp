@@ -140,6 +140,9 @@ struct cals_hip_engine {
   int out_wpe = 2;
   void *partial = nullptr;
   size_t partial_elems = 0;
+  double *hscratch = nullptr;  // models of rank > CALS_RMAX: H / L blocks of update_body_huge
+  size_t hscratch_blocks = 0;
+  int *d_hcounter = nullptr;
   void *krp_ws = nullptr;
   size_t krp_elems = 0;
   unsigned long long *dbg_clock = nullptr;  // CALS_MTTKRP_CLOCK=1: in-kernel clock stamps
@@ -752,7 +755,23 @@ int sweep_once(cals_hip_engine *e, bool evict_enabled, bool defer_changed = fals
     prof_end(e, pk);
   }
   int rank_max = 1;  // sizes the update kernel's LDS panel
-  for (auto t : e->registry) rank_max = std::max(rank_max, (int)e->models[t].rank);
+  size_t n_huge = 0;  // models above CALS_RMAX: the update needs a global H / L block each
+  for (auto t : e->registry) {
+    rank_max = std::max(rank_max, (int)e->models[t].rank);
+    if (e->models[t].rank > CALS_RMAX) n_huge++;
+  }
+  if (n_huge) {
+    if (e->prm.update_method == 1 || (e->prm.line_search && e->prm.line_search_method != 0))
+      return fail(e, CALS_HIP_ERR_ARG, "models of rank > 64 support the unconstrained update and the "
+                                       "NO_ERROR_CHECKING line search only");
+    if (n_huge > e->hscratch_blocks) {
+      if (e->hscratch) HIPCHK(hipFree(e->hscratch));
+      e->hscratch = nullptr;
+      e->hscratch_blocks = n_huge + n_huge / 2;
+      HIPCHK(hipMalloc((void **)&e->hscratch, e->hscratch_blocks * (size_t)CALS_GLD * CALS_GLD * sizeof(double)));
+    }
+    if (!e->d_hcounter) HIPCHK(hipMalloc((void **)&e->d_hcounter, sizeof(int)));
+  }
   if (e->sweep_log_on) {
     cals_hip_sweep_record rec{};
     rec.cols = R;
@@ -796,6 +815,9 @@ int sweep_once(cals_hip_engine *e, bool evict_enabled, bool defer_changed = fals
     u.X_norm = e->X_norm;
     u.jk_norms = e->d_jk_norms;
     u.dbg_trace = e->dbg_trace ? e->dbg_trace + 16 * 2048 - 64 : nullptr;  // last 64 entries of the trace
+    u.hscratch = e->hscratch;
+    u.hcounter = e->d_hcounter;
+    if (n_huge) HIPCHK(hipMemsetAsync(e->d_hcounter, 0, sizeof(int), e->stream));
     const int pk = prof_begin(e, 1, 0, LOG_UPDATE);
     if (!by_contract)
       HIPCHK(reduce_partials_launch(e->partial, g.T, e->lay[n].ldPart, (int)e->modes[n], (int)R,
@@ -1095,7 +1117,7 @@ int compress(cals_hip_engine *e) {
     };
     for (int n = 0; n < e->n_modes; n++) {
       add(e->factor[n], e->modes[n], wpe);
-      add(e->gram[n], CALS_RMAX, 2);
+      add(e->gram[n], CALS_GLD, 2);
       if (e->ls_allocated) {
         add(e->prev[n], e->modes[n], wpe);
         add(e->backup[n], e->modes[n], wpe);
@@ -1445,7 +1467,7 @@ int cals_hip_create_ex(cals_hip_engine **out, int n_modes, const int64_t *modes,
   int rc;
   for (int n = 0; n < n_modes; n++) {
     if ((rc = dev_alloc_elems(e, &e->factor[n], (size_t)(modes[n] * buffer_size)))) return rc;
-    if ((rc = dev_alloc(e, &e->gram[n], (size_t)(CALS_RMAX * buffer_size)))) return rc;
+    if ((rc = dev_alloc(e, &e->gram[n], (size_t)(CALS_GLD * buffer_size)))) return rc;
   }
   if ((rc = dev_alloc(e, &e->lambda, (size_t)buffer_size))) return rc;
   const size_t nb_max = (size_t)((buffer_size + CALS_BN - 1) / CALS_BN);
@@ -1620,6 +1642,8 @@ int cals_hip_destroy(cals_hip_engine *e) {
   if (e->h_out) (void)hipHostFree(e->h_out);
   if (e->ev_out) (void)hipEventDestroy(e->ev_out);
   fr(e->partial);
+  fr(e->hscratch);
+  fr(e->d_hcounter);
   fr(e->tree.Tbuf);
   fr(e->tree.Pt);
   fr(e->tree.d_changed);
@@ -2045,7 +2069,7 @@ int cals_hip_debug_get_lambda(cals_hip_engine *e, double *host) {
 int cals_hip_debug_get_gramian(cals_hip_engine *e, int mode, double *host) {
   if (!e || !host || mode < 0 || mode >= e->n_modes) return CALS_HIP_ERR_ARG;
   HIPCHK(hipSetDevice(e->device));  // a process may hold engines on several GPUs
-  HIPCHK(hipMemcpyAsync(host, e->gram[mode], sizeof(double) * (size_t)(CALS_RMAX * e->end),
+  HIPCHK(hipMemcpyAsync(host, e->gram[mode], sizeof(double) * (size_t)(CALS_GLD * e->end),
                         hipMemcpyDeviceToHost, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
   return CALS_HIP_OK;

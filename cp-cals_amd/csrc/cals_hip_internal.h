@@ -9,7 +9,10 @@
 #include <mutex>
 
 #define CALS_MAX_MODES 8
-#define CALS_RMAX 64          // rank limit per model; leading dimension of the Gramian stores
+#define CALS_RMAX 64          // ranks up to this: register / LDS update bodies, one-wave Cholesky, NNLS masks,
+                              // error-checking line search
+#define CALS_GLD 256          // leading dimension of the Gramian stores = rank limit per model; ranks above
+                              // CALS_RMAX take update_body_huge (H and the row solves through global memory)
 #define CALS_RFAST 32         // ranks up to this run the register-resident update bodies
 #define CALS_BN 128           // columns of the multi-factor per MTTKRP workgroup
 
@@ -140,7 +143,9 @@ struct UpdateArgs {
   int I;
   const void *partial;  // MTTKRP partial tiles (dtype)
   int NB, T, ldPart;
-  double *gram[CALS_MAX_MODES];  // column-indexed Gramian stores: CALS_RMAX x buffer, ld CALS_RMAX
+  double *gram[CALS_MAX_MODES];  // column-indexed Gramian stores: CALS_GLD x buffer, ld CALS_GLD
+  double *hscratch;    // ranks > CALS_RMAX in flight: one CALS_GLD x CALS_GLD block (H / L) per such model,
+  int *hcounter;       // handed out through this counter (zeroed before the launch)
   double *lambda;      // per column
   int n_modes, mode;
   int is_last;

@@ -15,7 +15,7 @@
 //
 // Everything a model owns is indexed by its first column `col` in the multi-factor buffers:
 // factor columns [col, col+r), lambda[col..], and an r x r Gramian per mode stored in columns
-// [col, col+r) of a CALS_RMAX x buffer matrix (ld = CALS_RMAX).
+// [col, col+r) of a CALS_GLD x buffer matrix (ld = CALS_GLD = the rank limit per model).
 #include "cals_hip_internal.h"
 
 #include <algorithm>
@@ -49,8 +49,8 @@ __device__ __forceinline__ v4d gramian_tile(PTR panel, int row0, int row1, long 
 
 // Gamma = P^T P for the I x r panel (ld) on the f64 matrix cores (r <= 32 in one pass): each k-step covers 4
 // rows; lane (lcol, krow) supplies P[i0+krow, lcol] as both the A and the B operand.
-// Written to g (ld = CALS_RMAX).  Must be called by a whole wave with EXEC all ones.
-template <typename T>
+// Written to g (ld = LDG: CALS_GLD for the Gramian stores).  Must be called by a whole wave with EXEC all ones.
+template <typename T, int LDG = CALS_GLD>
 __device__ __forceinline__ void gramian_wave(const T *panel, int rows, long long ld, int r,
                                              double *g, int lane) {
   const int krow = lane >> 4, lcol = lane & 15;
@@ -63,8 +63,8 @@ __device__ __forceinline__ void gramian_wave(const T *panel, int rows, long long
         for (int reg = 0; reg < 4; ++reg) {
           const int row = 16 * bi + krow + 4 * reg, cc = 16 * bj + lcol;
           if (row < r && cc < r) {
-            g[row + CALS_RMAX * cc] = t[reg];
-            g[cc + CALS_RMAX * row] = t[reg];
+            g[row + LDG * cc] = t[reg];
+            g[cc + LDG * row] = t[reg];
           }
         }
       }
@@ -88,13 +88,13 @@ __device__ __forceinline__ void gramian_wave(const T *panel, int rows, long long
 #pragma unroll
   for (int reg = 0; reg < 4; ++reg) {
     const int row = krow + 4 * reg;
-    if (row < r && lcol < r) g[row + CALS_RMAX * lcol] = a00[reg];
+    if (row < r && lcol < r) g[row + LDG * lcol] = a00[reg];
     if (two) {
       if (row < r && 16 + lcol < r) {
-        g[row + CALS_RMAX * (16 + lcol)] = a01[reg];
-        g[(16 + lcol) + CALS_RMAX * row] = a01[reg];
+        g[row + LDG * (16 + lcol)] = a01[reg];
+        g[(16 + lcol) + LDG * row] = a01[reg];
       }
-      if (16 + row < r && 16 + lcol < r) g[(16 + row) + CALS_RMAX * (16 + lcol)] = a11[reg];
+      if (16 + row < r && 16 + lcol < r) g[(16 + row) + LDG * (16 + lcol)] = a11[reg];
     }
   }
 }
@@ -155,8 +155,8 @@ __device__ __forceinline__ void gramian_rows(PTR panel, int row0, int row1, int 
 
 struct UpdShared {
   double Hs[CALS_RFAST * CALS_RFAST];
-  double dinv[CALS_RMAX];
-  double lams[CALS_RMAX];
+  double dinv[CALS_GLD];
+  double lams[CALS_GLD];
   double red[UPD_WAVES][CALS_RFAST][2];
   int redi[UPD_WAVES][CALS_RFAST];
   double redt[UPD_WAVES];
@@ -181,7 +181,7 @@ __device__ __attribute__((noinline)) void update_body(const UpdateArgs &a, int s
     const int i = e % r, j = e / r;
     double h = 1.0;
     for (int m = 0; m < a.n_modes; ++m)
-      if (m != a.mode) h *= a.gram[m][i + CALS_RMAX * (long long)(col + j)];
+      if (m != a.mode) h *= a.gram[m][i + CALS_GLD * (long long)(col + j)];
     Hs[i + RMAX * j] = h;
   }
   __syncthreads();
@@ -395,7 +395,7 @@ __device__ __attribute__((noinline)) void update_body(const UpdateArgs &a, int s
   }
   __syncthreads();
   {
-    double *g = a.gram[a.mode] + CALS_RMAX * (long long)col;
+    double *g = a.gram[a.mode] + CALS_GLD * (long long)col;
     const int tile = tid >> 6;  // 0: (0,0)  1: (0,1)+(1,0)  2: (1,1); wave 3 idles
     if (tile < 3) {
       const int krow = lane >> 4, lcol = lane & 15;
@@ -405,14 +405,14 @@ __device__ __attribute__((noinline)) void update_body(const UpdateArgs &a, int s
         const double v = ((sh.gp[0][tile][e] + sh.gp[1][tile][e]) + sh.gp[2][tile][e]) + sh.gp[3][tile][e];
         const int row = krow + 4 * reg;  // f64 C/D layout: D[row = krow + 4*reg][col = lcol]
         if (tile == 0) {
-          if (row < r && lcol < r) g[row + CALS_RMAX * lcol] = v;
+          if (row < r && lcol < r) g[row + CALS_GLD * lcol] = v;
         } else if (tile == 1) {
           if (row < r && 16 + lcol < r) {
-            g[row + CALS_RMAX * (16 + lcol)] = v;
-            g[(16 + lcol) + CALS_RMAX * row] = v;
+            g[row + CALS_GLD * (16 + lcol)] = v;
+            g[(16 + lcol) + CALS_GLD * row] = v;
           }
         } else {
-          if (16 + row < r && 16 + lcol < r) g[(16 + row) + CALS_RMAX * (16 + lcol)] = v;
+          if (16 + row < r && 16 + lcol < r) g[(16 + row) + CALS_GLD * (16 + lcol)] = v;
         }
       }
     }
@@ -425,7 +425,7 @@ __device__ __attribute__((noinline)) void update_body(const UpdateArgs &a, int s
     for (int e = tid; e < r * r; e += UPD_THREADS) {
       const int i = e % r, j = e / r;
       double h = 1.0;
-      for (int m = 0; m < a.n_modes; ++m) h *= a.gram[m][i + CALS_RMAX * (long long)(col + j)];
+      for (int m = 0; m < a.n_modes; ++m) h *= a.gram[m][i + CALS_GLD * (long long)(col + j)];
       t2 += lams[i] * lams[j] * h;
     }
     t2 = wave_sum(t2);
@@ -476,7 +476,7 @@ __device__ __attribute__((noinline)) void update_body_lds(const UpdateArgs &a, i
     const int i = e % r, j = e / r;
     double h = 1.0;
     for (int m = 0; m < a.n_modes; ++m)
-      if (m != a.mode) h *= a.gram[m][i + CALS_RMAX * (long long)(col + j)];
+      if (m != a.mode) h *= a.gram[m][i + CALS_GLD * (long long)(col + j)];
     Hs[i + RMAX * j] = h;
   }
   __syncthreads();
@@ -692,7 +692,7 @@ __device__ __attribute__((noinline)) void update_body_lds(const UpdateArgs &a, i
   }
   __syncthreads();
   {
-    double *g = a.gram[a.mode] + CALS_RMAX * (long long)col;
+    double *g = a.gram[a.mode] + CALS_GLD * (long long)col;
     const int tile = tid >> 6;
     if (tile < 3) {
       const int krow = lane >> 4, lcol = lane & 15;
@@ -702,14 +702,14 @@ __device__ __attribute__((noinline)) void update_body_lds(const UpdateArgs &a, i
         const double v = ((sh.gp[0][tile][e] + sh.gp[1][tile][e]) + sh.gp[2][tile][e]) + sh.gp[3][tile][e];
         const int row = krow + 4 * reg;
         if (tile == 0) {
-          if (row < r && lcol < r) g[row + CALS_RMAX * lcol] = v;
+          if (row < r && lcol < r) g[row + CALS_GLD * lcol] = v;
         } else if (tile == 1) {
           if (row < r && 16 + lcol < r) {
-            g[row + CALS_RMAX * (16 + lcol)] = v;
-            g[(16 + lcol) + CALS_RMAX * row] = v;
+            g[row + CALS_GLD * (16 + lcol)] = v;
+            g[(16 + lcol) + CALS_GLD * row] = v;
           }
         } else {
-          if (16 + row < r && 16 + lcol < r) g[(16 + row) + CALS_RMAX * (16 + lcol)] = v;
+          if (16 + row < r && 16 + lcol < r) g[(16 + row) + CALS_GLD * (16 + lcol)] = v;
         }
       }
     }
@@ -722,7 +722,7 @@ __device__ __attribute__((noinline)) void update_body_lds(const UpdateArgs &a, i
     for (int e = tid; e < r * r; e += UPD_THREADS) {
       const int i = e % r, j = e / r;
       double h = 1.0;
-      for (int m = 0; m < a.n_modes; ++m) h *= a.gram[m][i + CALS_RMAX * (long long)(col + j)];
+      for (int m = 0; m < a.n_modes; ++m) h *= a.gram[m][i + CALS_GLD * (long long)(col + j)];
       t2 += lams[i] * lams[j] * h;
     }
     t2 = wave_sum(t2);
@@ -764,7 +764,7 @@ __device__ __attribute__((noinline)) void update_body_big(const UpdateArgs &a, i
     const int i = e % r, j = e / r;
     double h = 1.0;
     for (int m = 0; m < a.n_modes; ++m)
-      if (m != a.mode) h *= a.gram[m][i + CALS_RMAX * (long long)(col + j)];
+      if (m != a.mode) h *= a.gram[m][i + CALS_GLD * (long long)(col + j)];
     Hb[i + RM * j] = h;
   }
   __syncthreads();
@@ -902,7 +902,7 @@ __device__ __attribute__((noinline)) void update_body_big(const UpdateArgs &a, i
   __syncthreads();
 
   {  // update_gramian, one 16 x 16 tile pair at a time, rows split over the waves
-    double *g = a.gram[a.mode] + CALS_RMAX * (long long)col;
+    double *g = a.gram[a.mode] + CALS_GLD * (long long)col;
     const int nt = (r + 15) >> 4;
     const int chunk = ((I + UPD_WAVES - 1) / UPD_WAVES + 3) / 4 * 4;
     const int row0 = wave * chunk, row1 = min(I, row0 + chunk);
@@ -920,8 +920,8 @@ __device__ __attribute__((noinline)) void update_body_big(const UpdateArgs &a, i
             const double v = ((gpb[e] + gpb[256 + e]) + gpb[512 + e]) + gpb[768 + e];
             const int row = 16 * bi + krow + 4 * reg, cc = 16 * bj + lcol;
             if (row < r && cc < r) {
-              g[row + CALS_RMAX * cc] = v;
-              g[cc + CALS_RMAX * row] = v;
+              g[row + CALS_GLD * cc] = v;
+              g[cc + CALS_GLD * row] = v;
             }
           }
         }
@@ -936,7 +936,223 @@ __device__ __attribute__((noinline)) void update_body_big(const UpdateArgs &a, i
     for (int e = tid; e < r * r; e += UPD_THREADS) {
       const int i = e % r, j = e / r;
       double h = 1.0;
-      for (int m = 0; m < a.n_modes; ++m) h *= a.gram[m][i + CALS_RMAX * (long long)(col + j)];
+      for (int m = 0; m < a.n_modes; ++m) h *= a.gram[m][i + CALS_GLD * (long long)(col + j)];
+      t2 += lams[i] * lams[j] * h;
+    }
+    t2 = wave_sum(t2);
+    __syncthreads();
+    if (lane == 0) sh.redt[wave] = t2;
+    __syncthreads();
+    if (tid == 0) {
+      t2 = sh.redt[0] + sh.redt[1] + sh.redt[2] + sh.redt[3];
+      const int jm = a.mt.jk_mode[slot];
+      const double xn = (jm >= 0) ? a.jk_norms[a.mt.jk_fiber[slot]] : a.X_norm;
+      const double e2 = fmax(xn * xn + t2 - 2.0 * t3, 0.0);
+      const double err = sqrt(e2);
+      a.mt.err[slot] = err;
+      const double of = a.mt.fit[slot];
+      a.mt.old_fit[slot] = of;
+      a.mt.fit[slot] = 1.0 - fabs(err) / a.X_norm;
+    }
+  }
+}
+
+// Ranks 65..CALS_GLD: no register file or LDS holds an r x r matrix or a factor row of this size, so H / L
+// live in a global scratch block per workgroup (a.hscratch, L2 resident) and every row is solved IN PLACE
+// in the factor panel (column accesses are coalesced over the rows a wavefront holds; L entries are
+// broadcast loads).  Same operations as update_body_big -- unblocked Cholesky in dpotf2's order, dtrsm
+// Right/Lower/Trans then Right/Lower/NoTrans row by row, |L^-1 g_i|^2 for the error term -- with the whole
+// workgroup on the factorisation (lane = row no longer fits one wave).  Built to be right, not fast: the
+// reference's typical ranks are <= 20 and everything up to 64 runs the bodies above.  The NNLS update and
+// the error-checking line search stay limited to CALS_RMAX (the engine rejects the combination).
+template <typename T>
+__device__ __attribute__((noinline)) void update_body_huge(const UpdateArgs &a, int slot, int r,
+                                                           UpdShared &sh) {
+  constexpr int LD = CALS_GLD;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int col = a.mt.col[slot];
+  const long long iters = a.mt.iters[slot];
+  const int jkf = (a.mt.jk_mode[slot] == a.mode) ? a.mt.jk_fiber[slot] : -1;
+  const int I = a.I;
+  double *gpb = reinterpret_cast<double *>(upd_dyn);         // [UPD_WAVES][256] partial Gramian tiles
+  __shared__ double s_piv;
+  __shared__ int s_info, s_block;
+  // scratch blocks are handed out in arrival order (the engine sizes the pool by the number of such models
+  // in flight and zeroes the counter before the launch)
+  if (tid == 0) s_block = atomicAdd(a.hcounter, 1);
+  __syncthreads();
+  double *H = a.hscratch + (long long)s_block * LD * LD;  // r x r, ld LD
+
+  for (int e = tid; e < r * r; e += UPD_THREADS) {
+    const int i = e % r, j = e / r;
+    double h = 1.0;
+    for (int m = 0; m < a.n_modes; ++m)
+      if (m != a.mode) h *= a.gram[m][i + CALS_GLD * (long long)(col + j)];
+    H[i + LD * j] = h;
+  }
+  if (tid == 0) s_info = 0;
+  __threadfence_block();
+  __syncthreads();
+  // dpotf2, column j: s_i = H[i][j] - sum_{k<j} L[i][k] L[j][k] for the rows i >= j, one row per thread
+  for (int j = 0; j < r; ++j) {
+    double sv[(CALS_GLD + UPD_THREADS - 1) / UPD_THREADS];
+#pragma unroll
+    for (int q = 0; q < (CALS_GLD + UPD_THREADS - 1) / UPD_THREADS; ++q) {
+      const int i = j + tid + q * UPD_THREADS;
+      sv[q] = 0.0;
+      if (i < r) {
+        double s_ = H[i + LD * j];
+        for (int k = 0; k < j; ++k) s_ -= H[i + LD * k] * H[j + LD * k];
+        sv[q] = s_;
+        if (i == j) s_piv = s_;
+      }
+    }
+    __syncthreads();
+    const double ajj = s_piv;
+    if (!(ajj > 0.0)) {  // info != 0: stop, go on with whatever is in H (update.cpp:183-185 only logs)
+      if (tid == 0) {
+        H[j + LD * j] = ajj;
+        s_info = j + 1;
+      }
+      break;
+    }
+    const double ljj = sqrt(ajj);
+#pragma unroll
+    for (int q = 0; q < (CALS_GLD + UPD_THREADS - 1) / UPD_THREADS; ++q) {
+      const int i = j + tid + q * UPD_THREADS;
+      if (i == j)
+        H[j + LD * j] = ljj;
+      else if (i < r)
+        H[i + LD * j] = sv[q] / ljj;
+    }
+    __threadfence_block();
+    __syncthreads();
+  }
+  __syncthreads();
+  for (int k = tid; k < r; k += UPD_THREADS) sh.dinv[k] = 1.0 / H[k + LD * k];
+  if (tid == 0) a.mt.potrf_info[slot] = s_info;
+  __threadfence_block();
+  __syncthreads();
+  const double *dinv = sh.dinv;
+
+  T *fac = static_cast<T *>(a.factor) + (long long)I * col;
+  const bool first = (iters == 1);
+  double t3 = 0.0;
+  for (int i = tid; i < I; i += UPD_THREADS) {
+    T *x = fac + i;  // row i: x[c] at x[I * c]
+    // B := B * inv(L^T): forward substitution along the row
+    for (int k = 0; k < r; ++k) {
+      const double xk = dinv[k] * (double)x[(long long)I * k];
+      x[(long long)I * k] = (T)xk;
+      for (int j = k + 1; j < r; ++j)
+        x[(long long)I * j] = (T)((double)x[(long long)I * j] - H[j + LD * k] * xk);
+    }
+    if (i != jkf)
+      for (int c = 0; c < r; ++c) {
+        const double v = (double)x[(long long)I * c];
+        t3 += v * v;
+      }
+    // B := B * inv(L): backward substitution
+    for (int j = r - 1; j >= 0; --j) {
+      double s_ = (double)x[(long long)I * j];
+      for (int k = j + 1; k < r; ++k) s_ -= H[k + LD * j] * (double)x[(long long)I * k];
+      x[(long long)I * j] = (T)(dinv[j] * s_);
+    }
+    if (i == jkf)
+      for (int c = 0; c < r; ++c) x[(long long)I * c] = (T)((double)x[(long long)I * c] * 0.0);
+  }
+  t3 = wave_sum(t3);
+  if (lane == 0) sh.redt[wave] = t3;
+  __threadfence_block();
+  __syncthreads();
+  t3 = sh.redt[0] + sh.redt[1] + sh.redt[2] + sh.redt[3];
+
+  for (int c = wave; c < r; c += UPD_WAVES) {  // column scales (Ktensor::normalize(mode, iteration))
+    const T *cp = fac + (long long)I * c;
+    double lam;
+    if (first) {
+      double ss = 0.0;
+      for (int i = lane; i < I; i += 64) {
+        const double x = (double)cp[i];
+        ss += x * x;
+      }
+      lam = sqrt(wave_sum(ss));
+    } else {
+      double m = -1.0, v = 0.0;
+      int ix = 0x7fffffff;
+      for (int i = lane; i < I; i += 64) {
+        const double x = (double)cp[i];
+        const double ax = fabs(x);
+        if (ax > m) {
+          m = ax;
+          v = x;
+          ix = i;
+        }
+      }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        const double m2 = __shfl_xor(m, off);
+        const double v2 = __shfl_xor(v, off);
+        const int i2 = __shfl_xor(ix, off);
+        const bool take = (m2 > m) || (m2 == m && i2 < ix);
+        m = take ? m2 : m;
+        v = take ? v2 : v;
+        ix = take ? i2 : ix;
+      }
+      lam = v;
+    }
+    if (lane == 0) {
+      sh.lams[c] = lam;
+      a.lambda[col + c] = lam;
+    }
+  }
+  __syncthreads();
+  const double *lams = sh.lams;
+  for (int c = 0; c < r; ++c) {
+    const double lam = lams[c];
+    if (lam != 0.0)
+      for (int i = tid; i < I; i += UPD_THREADS)
+        fac[i + (long long)I * c] = (T)((1.0 / lam) * (double)fac[i + (long long)I * c]);
+  }
+  __threadfence_block();
+  __syncthreads();
+
+  {  // update_gramian, one 16 x 16 tile pair at a time, rows split over the waves
+    double *g = a.gram[a.mode] + CALS_GLD * (long long)col;
+    const int nt = (r + 15) >> 4;
+    const int chunk = ((I + UPD_WAVES - 1) / UPD_WAVES + 3) / 4 * 4;
+    const int row0 = wave * chunk, row1 = min(I, row0 + chunk);
+    const int krow = lane >> 4, lcol = lane & 15;
+    for (int bi = 0; bi < nt; ++bi)
+      for (int bj = bi; bj < nt; ++bj) {
+        const v4d t = gramian_tile((const T *)fac, row0, row1, (long long)I, r, lane, bi, bj);
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) gpb[wave * 256 + lane * 4 + reg] = t[reg];
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+          for (int reg = 0; reg < 4; ++reg) {
+            const int e = lane * 4 + reg;
+            const double v = ((gpb[e] + gpb[256 + e]) + gpb[512 + e]) + gpb[768 + e];
+            const int row = 16 * bi + krow + 4 * reg, cc = 16 * bj + lcol;
+            if (row < r && cc < r) {
+              g[row + CALS_GLD * cc] = v;
+              g[cc + CALS_GLD * row] = v;
+            }
+          }
+        }
+        __syncthreads();
+      }
+  }
+
+  if (a.is_last) {
+    __threadfence_block();
+    __syncthreads();
+    double t2 = 0.0;
+    for (int e = tid; e < r * r; e += UPD_THREADS) {
+      const int i = e % r, j = e / r;
+      double h = 1.0;
+      for (int m = 0; m < a.n_modes; ++m) h *= a.gram[m][i + CALS_GLD * (long long)(col + j)];
       t2 += lams[i] * lams[j] * h;
     }
     t2 = wave_sum(t2);
@@ -962,6 +1178,10 @@ __global__ void __launch_bounds__(UPD_THREADS, 1) update_kernel(const UpdateArgs
   __shared__ UpdShared sh;
   const int slot = a.slots[blockIdx.x];
   const int r = a.mt.rank[slot];
+  if (r > CALS_RMAX) {
+    update_body_huge<T>(a, slot, r, sh);
+    return;
+  }
   if (r > CALS_RFAST) {
     update_body_big<T>(a, slot, r, sh);
     return;
@@ -1182,7 +1402,7 @@ __global__ void __launch_bounds__(64) gram_init_kernel(const GramInitArgs a) {
   const int col = a.mt.col[slot];
   const int r = a.mt.rank[slot];
   gramian_wave<T>(static_cast<const T *>(a.factor[m]) + (long long)a.I[m] * col, a.I[m], a.I[m], r,
-                  a.gram[m] + CALS_RMAX * (long long)col, threadIdx.x);
+                  a.gram[m] + CALS_GLD * (long long)col, threadIdx.x);
 }
 
 hipError_t gram_init_launch(const GramInitArgs &a, hipStream_t st) {
@@ -1219,7 +1439,7 @@ __global__ void __launch_bounds__(256) ls_kernel(const LsArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int col = a.mt.col[slot], r = a.mt.rank[slot];
   const long long iters = a.mt.iters[slot];
-  __shared__ double s_lam[CALS_RMAX];
+  __shared__ double s_lam[CALS_GLD];
   if (tid == 0) a.mt.flags[slot] = 0;
   // "Make sure extrapolation doesn't happen right before a Ktensor is evicted" (cals.cpp:314-316)
   if (iters >= a.max_iter) return;
@@ -1320,7 +1540,7 @@ __global__ void __launch_bounds__(256) ls_kernel(const LsArgs a) {
   if (regram) {  // update_gramians
     for (int m = wave; m < a.n_modes; m += 4)
       gramian_wave<T>(static_cast<const T *>(a.factor[m]) + (long long)a.I[m] * col, a.I[m], a.I[m], r,
-                      a.gram[m] + CALS_RMAX * (long long)col, lane);
+                      a.gram[m] + CALS_GLD * (long long)col, lane);
   }
   if (tid == 0) {
     a.mt.ls_iter[slot] = ls_iter;
@@ -1385,8 +1605,8 @@ __global__ void __launch_bounds__(256) ls_ec_decide_kernel(const LsArgs a) {
   // t2 = sum_ij l_i l_j prod_m (F_m^T F_m)_ij over the candidate's factors (in a.prev)
   for (int m = 0; m < a.n_modes; ++m) {
     if (wave == 0)
-      gramian_wave<T>(static_cast<const T *>(a.prev[m]) + (long long)a.I[m] * col, a.I[m], a.I[m], r,
-                      m == 0 ? H : tmp, lane);
+      gramian_wave<T, CALS_RMAX>(static_cast<const T *>(a.prev[m]) + (long long)a.I[m] * col, a.I[m], a.I[m], r,
+                                 m == 0 ? H : tmp, lane);
     __syncthreads();
     if (m > 0)
       for (int e = tid; e < r * r; e += 256) {
@@ -1447,7 +1667,7 @@ __global__ void __launch_bounds__(256) ls_ec_decide_kernel(const LsArgs a) {
   __syncthreads();
   for (int m = wave; m < a.n_modes; m += 4)
     gramian_wave<T>(static_cast<const T *>(a.factor[m]) + (long long)a.I[m] * col, a.I[m], a.I[m], r,
-                    a.gram[m] + CALS_RMAX * (long long)col, lane);
+                    a.gram[m] + CALS_GLD * (long long)col, lane);
   if (tid == 0) {
     a.mt.err[slot] = error;
     const double of = a.mt.fit[slot];

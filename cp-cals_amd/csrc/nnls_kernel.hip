@@ -212,7 +212,7 @@ __global__ void __launch_bounds__(256) nnls_kernel(const NnlsArgs a) {
     const int i = e % r, j = e / r;
     double h = 1.0;
     for (int m = 0; m < a.n_modes; ++m)
-      if (m != a.mode) h *= a.gram[m][i + CALS_RMAX * (long long)(col + j)];
+      if (m != a.mode) h *= a.gram[m][i + CALS_GLD * (long long)(col + j)];
     Hs[i + r * j] = h;
   }
   __syncthreads();

@@ -20,7 +20,9 @@ extern "C" {
 #endif
 
 #define CALS_HIP_MAX_MODES 8
-#define CALS_HIP_MAX_RANK 64 /* per-model rank limit (ranks above 32 take a slower update body) */
+#define CALS_HIP_MAX_RANK 256 /* per-model rank limit.  Ranks 1..32: register / LDS update bodies; 33..64: H in
+                               * LDS, rows in registers; 65..256: H and the row solves through global memory
+                               * (unconstrained update + NO_ERROR_CHECKING line search only) */
 
 /* status codes */
 enum {

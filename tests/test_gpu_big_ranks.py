@@ -1,0 +1,118 @@
+"""Models of rank 65..256 (the reference is unbounded, include/ktensor.h; round 1 stopped at 64):
+update_body_huge keeps H / L in a global scratch block per model and solves every factor row in place.
+Same oracle, same tolerances as the other bodies; mixed with small models in one buffer, queued,
+jackknifed, with the NO_ERROR_CHECKING line search, under every MTTKRP plan, in fp32 storage."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import make_models, rel
+from test_gpu_parity import TOL_KERNEL, TOL_RUN, _assert_models_match, _run_both, engine_with
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("ranks", [[65], [100], [128], [7, 200, 70, 20], [256]])
+def test_single_sweeps_state_vs_oracle(cc, oracle, inputs, ranks):
+    modes = [90, 80, 70]
+    X = inputs.tensor(modes, 6)
+    prm = cc.default_params(max_iterations=100, force_max_iter=1)
+    e, gm, base = engine_with(cc, inputs, modes, ranks, X, params=prm)
+    e.admit()
+    e.sweep(2)
+    om = [oracle.Model(fs, lam) for fs, lam, _ in base]
+    oracle.cp_cals(X, modes, om, oracle.default_params(max_iterations=2, force_max_iter=1,
+                                                       buffer_size=sum(ranks), mttkrp_method=oracle.MTTKRP))
+    lam = e.debug_lambda()
+    col = 0
+    for m, g in zip(om, gm):
+        r = m.rank
+        for n in range(3):
+            F = e.debug_factor(n)[:, col:col + r]
+            assert rel(F, m.factors[n]) < 1e-10      # condition of a 256 x 256 Hadamard of Gramians
+            Gm = e.debug_gramian(n)[:r, col:col + r]
+            assert rel(Gm, m.factors[n].T @ m.factors[n]) < 1e-10
+        assert rel(lam[col:col + r], m.lam) < 1e-10
+        st, c = e.debug_status(g)
+        assert c == col and st.iters == 3
+        assert abs(st.approx_error - m.error) <= 1e-9 * max(1.0, m.error)
+        col += r
+    e.close()
+
+
+@pytest.mark.parametrize("plan", ["M", "A", "B", "0"])
+def test_forced_iterations_line_search_and_plans(cc, oracle, inputs, plan):
+    old = os.environ.get("CALS_HIP_TREE")
+    os.environ["CALS_HIP_TREE"] = plan
+    try:
+        modes, ranks = [60, 50, 45], [70, 3, 96, 20, 65]
+        X = inputs.low_rank_tensor(modes, 8, seed=3)[0] + 0.2 * inputs.tensor(modes, 4)
+        gm, om, rep, ro = _run_both(cc, oracle, inputs, modes, ranks, X, 9, line_search=1, line_search_interval=3)
+    finally:
+        if old is None:
+            os.environ.pop("CALS_HIP_TREE", None)
+        else:
+            os.environ["CALS_HIP_TREE"] = old
+    assert (rep.iter, rep.ls_performed, rep.ls_failed) == (ro.iter, ro.ls_performed, ro.ls_failed)
+    assert rep.ls_performed > 0
+    _assert_models_match(gm, om, ro.X_norm ** 2)
+
+
+def test_queue_eviction_compress_with_mixed_ranks(cc, oracle, inputs):
+    """big and small models through a buffer that holds two big ones at most: admission, tolerance-driven
+    eviction and compress move 256-row Gramian columns next to 64-row ones."""
+    modes = [40, 35, 30]
+    ranks = [80, 5, 66, 12, 90, 3, 70, 20, 100, 1]
+    X = inputs.low_rank_tensor(modes, 4, seed=5)[0] + 0.1 * inputs.tensor(modes, 7)
+    gm, om, rep, ro = _run_both(cc, oracle, inputs, modes, ranks, X, 30, buffer=180, force_max_iter=0, tol=1e-5)
+    assert (rep.iter, rep.n_ktensors, rep.ktensor_comp_sum) == (ro.iter, ro.n_ktensors, ro.ktensor_comp_sum)
+    for a, b in zip(gm, om):
+        assert a.iters == b.iters
+    _assert_models_match(gm, om, ro.X_norm ** 2, tol=1e-7)
+
+
+def test_jackknife_and_fp32_storage(cc, oracle, inputs):
+    modes, ranks = [50, 44, 40], [72, 9]
+    X = inputs.tensor(modes, 2)
+    jk = [(0, 3), (0, 17)]
+    gm, om, rep, ro = _run_both(cc, oracle, inputs, modes, ranks, X, 6, jk=jk)
+    _assert_models_match(gm, om, ro.X_norm ** 2)
+    for (mode, fiber), m in zip(jk, gm):
+        assert not m.factors[mode][fiber, :].any()
+    # fp32 storage: the in-place row solves round to float at every step -- stated tolerance 5e-3 after 4 sweeps
+    base = make_models(inputs, modes, ranks, seed=1)
+    e = cc.Engine(modes, sum(ranks), dtype="f32")
+    e.set_tensor(X)
+    e.set_params(cc.default_params(max_iterations=4, force_max_iter=1))
+    g32 = [cc.Model([f.copy() for f in fs], lam.copy()) for fs, lam, _ in base]
+    for m in g32:
+        e.enqueue(m)
+    e.run()
+    e.close()
+    o64 = [oracle.Model([f.copy() for f in fs], lam.copy()) for fs, lam, _ in base]
+    oracle.cp_cals(X, modes, o64, oracle.default_params(max_iterations=4, force_max_iter=1, buffer_size=sum(ranks),
+                                                        mttkrp_method=oracle.MTTKRP))
+    for a, b in zip(g32, o64):
+        for fa, fb in zip(a.factors, b.factors):
+            assert rel(fa, fb) < 5e-3
+
+
+def test_unsupported_combinations_fail_loudly(cc, inputs):
+    modes = [30, 20, 10]
+    X = inputs.tensor(modes, 1)
+    for kw in (dict(update_method=1), dict(line_search=1, line_search_method=1)):
+        e = cc.Engine(modes, 80)
+        e.set_tensor(X)
+        e.set_params(cc.default_params(max_iterations=3, force_max_iter=1, **kw))
+        (fs, lam), = inputs.model_factors(modes, [70], 1)
+        e.enqueue(cc.Model(fs, lam))
+        with pytest.raises(cc.CalsHipError) as ei:
+            e.run()
+        assert "rank > 64" in str(ei.value)
+        e.close()
+    e = cc.Engine(modes, 300)
+    (fs, lam), = inputs.model_factors(modes, [257], 1)
+    with pytest.raises(cc.CalsHipError):
+        e.enqueue(cc.Model(fs, lam))
+    e.close()
