@@ -60,8 +60,8 @@ static void c_abi_life_cycles(int dtype) {
   for (int round = 0; round < 6; round++) {
     std::vector<int> ranks;
     const int n_models = 20 + (int)(gen() % 60);
-    for (int k = 0; k < n_models; k++) ranks.push_back(1 + (int)(gen() % (round == 5 ? 64 : 12)));
-    const int64_t buffer = round == 5 ? 130 : 16 + (int64_t)(gen() % 40);
+    for (int k = 0; k < n_models; k++) ranks.push_back(1 + (int)(gen() % (round == 5 ? 150 : 12)));
+    const int64_t buffer = round == 5 ? 400 : 16 + (int64_t)(gen() % 40);
     auto models = make_models(modes, ranks, 100 + round);
     cals_hip_engine *e = nullptr;
     CHECK(cals_hip_create_ex(&e, 3, modes.data(), buffer, 0, dtype) == CALS_HIP_OK);
@@ -149,7 +149,7 @@ static void stepwise_api() {
   int64_t n = 0;
   CHECK(cals_hip_admit(e, &n) == CALS_HIP_OK && n == 3 && cals_hip_active_cols(e) == 21);
   CHECK(cals_hip_sweep(e, 4) == CALS_HIP_OK);
-  std::vector<double> F(12 * 21), lam(21), G(64 * 21);
+  std::vector<double> F(12 * 21), lam(21), G((size_t)CALS_HIP_MAX_RANK * 21);
   CHECK(cals_hip_debug_get_factor(e, 0, F.data()) == CALS_HIP_OK && F[0] == models[0].f0[0][0]);
   CHECK(cals_hip_debug_get_lambda(e, lam.data()) == CALS_HIP_OK);
   CHECK(cals_hip_debug_get_gramian(e, 3, G.data()) == CALS_HIP_OK);
