@@ -723,6 +723,8 @@ LsArgs make_ls_args(cals_hip_engine *e) {
   a.dtype = e->dtype;
   a.Gs = e->backup[0];
   a.X_norm = e->X_norm;
+  a.hscratch = e->hscratch;
+  a.hcounter = e->d_hcounter;
   a.lambda = e->lambda;
   a.prev_lambda = e->prev_lambda;
   a.backup_lambda = e->backup_lambda;
@@ -761,9 +763,10 @@ int sweep_once(cals_hip_engine *e, bool evict_enabled, bool defer_changed = fals
     if (e->models[t].rank > CALS_RMAX) n_huge++;
   }
   if (n_huge) {
-    if (e->prm.update_method == 1 || (e->prm.line_search && e->prm.line_search_method != 0))
-      return fail(e, CALS_HIP_ERR_ARG, "models of rank > 64 support the unconstrained update and the "
-                                       "NO_ERROR_CHECKING line search only");
+    if (e->prm.update_method == 1)
+      return fail(e, CALS_HIP_ERR_ARG, "models of rank > 64 support the unconstrained update only (the NNLS "
+                                       "kernel keeps a row's active set in one 64-bit mask)");
+    if (e->prm.line_search && e->prm.line_search_method != 0) n_huge *= 2;  // H and one Gramian at a time
     if (n_huge > e->hscratch_blocks) {
       if (e->hscratch) HIPCHK(hipFree(e->hscratch));
       e->hscratch = nullptr;
@@ -873,6 +876,7 @@ int sweep_once(cals_hip_engine *e, bool evict_enabled, bool defer_changed = fals
         if ((rc = launch_mttkrp(e, 0, R, &g, e->prev))) return rc;
         HIPCHK(reduce_partials_launch(e->partial, g.T, e->lay[0].ldPart, (int)e->modes[0], (int)R,
                                       e->backup[0], e->dtype, e->stream));
+        if (n_huge) HIPCHK(hipMemsetAsync(e->d_hcounter, 0, sizeof(int), e->stream));
         HIPCHK(ls_ec_decide_launch(la, e->stream));
       }
     }

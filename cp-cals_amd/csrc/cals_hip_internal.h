@@ -229,6 +229,9 @@ struct LsArgs {
   // ERROR_CHECKING line search (ls_ec_*): MTTKRP of mode 0 with the extrapolated factors, I[0] x R
   const void *Gs;
   double X_norm;
+  // error-checking line search of models above CALS_RMAX: two CALS_GLD^2 scratch blocks per such model
+  double *hscratch;
+  int *hcounter;
   // NNLS: Ktensor::copy carries the active sets along (src/ktensor.cpp:174); null otherwise
   unsigned long long *act[CALS_MAX_MODES], *act_backup[CALS_MAX_MODES];
 };

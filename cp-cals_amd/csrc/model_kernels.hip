@@ -963,8 +963,8 @@ __device__ __attribute__((noinline)) void update_body_big(const UpdateArgs &a, i
 // broadcast loads).  Same operations as update_body_big -- unblocked Cholesky in dpotf2's order, dtrsm
 // Right/Lower/Trans then Right/Lower/NoTrans row by row, |L^-1 g_i|^2 for the error term -- with the whole
 // workgroup on the factorisation (lane = row no longer fits one wave).  Built to be right, not fast: the
-// reference's typical ranks are <= 20 and everything up to 64 runs the bodies above.  The NNLS update and
-// the error-checking line search stay limited to CALS_RMAX (the engine rejects the combination).
+// reference's typical ranks are <= 20 and everything up to 64 runs the bodies above.  The NNLS update stays
+// limited to CALS_RMAX (the engine rejects the combination).
 template <typename T>
 __device__ __attribute__((noinline)) void update_body_huge(const UpdateArgs &a, int slot, int r,
                                                            UpdShared &sh) {
@@ -1598,27 +1598,40 @@ __global__ void __launch_bounds__(256) ls_ec_decide_kernel(const LsArgs a) {
   if (!(a.mt.flags[slot] & 1)) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int col = a.mt.col[slot], r = a.mt.rank[slot];
-  double *H = reinterpret_cast<double *>(ec_dyn);   // r x r, ld CALS_RMAX: hadamard of the Gramians
-  double *tmp = H + CALS_RMAX * CALS_RMAX;          // one Gramian at a time
+  // r x r Hadamard of the candidate's Gramians (H) and one Gramian at a time (tmp): in LDS, ld CALS_RMAX,
+  // up to rank CALS_RMAX; above it two CALS_GLD x CALS_GLD blocks of the engine's global scratch, handed out
+  // through a counter like update_body_huge's
   __shared__ double red[4];
-  __shared__ int s_accept;
+  __shared__ int s_accept, s_block;
+  const bool huge = r > CALS_RMAX;
+  if (huge && tid == 0) s_block = atomicAdd(a.hcounter, 2);
+  __syncthreads();
+  const int ldh = huge ? CALS_GLD : CALS_RMAX;
+  double *H = huge ? a.hscratch + (long long)s_block * CALS_GLD * CALS_GLD : reinterpret_cast<double *>(ec_dyn);
+  double *tmp = huge ? H + (long long)CALS_GLD * CALS_GLD : H + CALS_RMAX * CALS_RMAX;
   // t2 = sum_ij l_i l_j prod_m (F_m^T F_m)_ij over the candidate's factors (in a.prev)
   for (int m = 0; m < a.n_modes; ++m) {
-    if (wave == 0)
-      gramian_wave<T, CALS_RMAX>(static_cast<const T *>(a.prev[m]) + (long long)a.I[m] * col, a.I[m], a.I[m], r,
-                                 m == 0 ? H : tmp, lane);
+    if (wave == 0) {
+      const T *panel = static_cast<const T *>(a.prev[m]) + (long long)a.I[m] * col;
+      if (huge)
+        gramian_wave<T, CALS_GLD>(panel, a.I[m], a.I[m], r, m == 0 ? H : tmp, lane);
+      else
+        gramian_wave<T, CALS_RMAX>(panel, a.I[m], a.I[m], r, m == 0 ? H : tmp, lane);
+    }
+    __threadfence_block();
     __syncthreads();
     if (m > 0)
       for (int e = tid; e < r * r; e += 256) {
         const int i = e % r, j = e / r;
-        H[i + CALS_RMAX * j] *= tmp[i + CALS_RMAX * j];
+        H[i + ldh * j] *= tmp[i + ldh * j];
       }
+    __threadfence_block();
     __syncthreads();
   }
   double t2 = 0.0, t3 = 0.0;
   for (int e = tid; e < r * r; e += 256) {
     const int i = e % r, j = e / r;
-    t2 += a.prev_lambda[col + i] * a.prev_lambda[col + j] * H[i + CALS_RMAX * j];
+    t2 += a.prev_lambda[col + i] * a.prev_lambda[col + j] * H[i + ldh * j];
   }
   {
     const int I0 = a.I[0];

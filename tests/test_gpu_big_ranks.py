@@ -1,7 +1,8 @@
 """Models of rank 65..256 (the reference is unbounded, include/ktensor.h; round 1 stopped at 64):
 update_body_huge keeps H / L in a global scratch block per model and solves every factor row in place.
 Same oracle, same tolerances as the other bodies; mixed with small models in one buffer, queued,
-jackknifed, with the NO_ERROR_CHECKING line search, under every MTTKRP plan, in fp32 storage."""
+jackknifed, with both line-search methods, under every MTTKRP plan, in fp32 storage.  NNLS stays limited to
+rank 64 (64-bit active-set masks) and says so."""
 import os
 
 import numpy as np
@@ -98,10 +99,23 @@ def test_jackknife_and_fp32_storage(cc, oracle, inputs):
             assert rel(fa, fb) < 5e-3
 
 
+def test_error_checking_line_search(cc, oracle, inputs):
+    """ls::ERROR_CHECKING_SERIAL with models above rank 64: the candidate's r x r Hadamard of Gramians
+    goes through two global scratch blocks instead of LDS."""
+    modes, ranks = [26, 22, 19], [70, 4, 66, 12]
+    X = inputs.low_rank_tensor(modes, 6, seed=31)[0] + 0.1 * inputs.tensor(modes, 8)
+    gm, om, rep, ro = _run_both(cc, oracle, inputs, modes, ranks, X, 30, force_max_iter=0, tol=1e-6,
+                                line_search=1, line_search_interval=4, line_search_method=1)
+    assert rep.iter == ro.iter
+    assert (rep.ls_performed, rep.ls_failed) == (ro.ls_performed, ro.ls_failed)
+    assert rep.ls_performed > 0
+    _assert_models_match(gm, om, ro.X_norm ** 2, tol=1e-7)
+
+
 def test_unsupported_combinations_fail_loudly(cc, inputs):
     modes = [30, 20, 10]
     X = inputs.tensor(modes, 1)
-    for kw in (dict(update_method=1), dict(line_search=1, line_search_method=1)):
+    for kw in (dict(update_method=1),):
         e = cc.Engine(modes, 80)
         e.set_tensor(X)
         e.set_params(cc.default_params(max_iterations=3, force_max_iter=1, **kw))
