@@ -158,37 +158,31 @@ int main(int argc, char *argv[]) {
       m.set_jk_fiber(NAN);
     }
   {
-    auto &kt = fitted_ktensors[0];
-    auto &Bov = kt.get_factor(1);
-    auto &Cov = kt.get_factor(2);
-    for (dim_t m = 0; m < tensor.get_modes()[0]; m++) {
-      auto &kt_jk = cals_jk_input[0][m];
-      auto const comp_n = kt.get_components();
-      auto M = cals::Matrix(comp_n, comp_n);
-      auto Mt = cals::Matrix(comp_n, comp_n);
-      auto &Bm = kt_jk.get_factor(1);
-      auto &Cm = kt_jk.get_factor(2);
-      cblas_dgemm(CblasColMajor, CblasTrans, CblasNoTrans, comp_n, comp_n, tensor.get_modes()[1], 1.0, Bov.get_data(),
-                  Bov.get_col_stride(), Bm.get_data(), Bm.get_col_stride(), 0.0, M.get_data(), M.get_col_stride());
-      cblas_dgemm(CblasColMajor, CblasTrans, CblasNoTrans, comp_n, comp_n, tensor.get_modes()[2], 1.0, Cov.get_data(),
-                  Cov.get_col_stride(), Cm.get_data(), Cm.get_col_stride(), 0.0, Mt.get_data(), Mt.get_col_stride());
-      for (dim_t ii = 0; ii < M.get_n_elements(); ii++) M[ii] += Mt[ii];
-      vector<int64_t> init_v(comp_n), solved_v(comp_n);
-      bad += check(solve_rectangular_linear_sum_assignment(comp_n, comp_n, M.get_data(), true, init_v.data(),
-                                                           solved_v.data()) == 0,
+    // column matching of every replica against the overall model, spelled with the calls the MEX glue uses:
+    // cblas_dgemm on factor data, the assignment solver on the column-major buffer, single-column Matrix views
+    Ktensor &overall = fitted_ktensors[0];
+    const dim_t nc = overall.get_components();
+    auto overlap = [&](cals::Matrix &out, const cals::Matrix &ov, const cals::Matrix &rep) {
+      cblas_dgemm(CblasColMajor, CblasTrans, CblasNoTrans, nc, nc, ov.get_rows(), 1.0, ov.get_data(), ov.get_col_stride(),
+                  rep.get_data(), rep.get_col_stride(), 0.0, out.get_data(), out.get_col_stride());
+    };
+    for (dim_t slice = 0; slice < tensor.get_modes()[0]; slice++) {
+      Ktensor &replica = cals_jk_input[0][slice];
+      cals::Matrix score(nc, nc), part(nc, nc);
+      overlap(score, overall.get_factor(1), replica.get_factor(1));
+      overlap(part, overall.get_factor(2), replica.get_factor(2));
+      for (dim_t e = 0; e < score.get_n_elements(); e++) score[e] += part[e];
+      vector<int64_t> rows(nc), match(nc);
+      bad += check(solve_rectangular_linear_sum_assignment(nc, nc, score.get_data(), true, rows.data(), match.data()) == 0,
                    "assignment solver");
-      for (dim_t mode = 0; mode < kt.get_n_modes(); mode++) {
-        auto &factor = kt_jk.get_factor(mode);
-        auto copy_factor = cals::Matrix(factor.get_rows(), factor.get_cols());
-        copy_factor.copy(factor);
-        auto const stride = factor.get_col_stride();
-        auto curr_col_id = 0;
-        for (auto &swap_col_id : solved_v) {
-          if (swap_col_id != curr_col_id)
-            cals::Matrix(factor.get_rows(), 1, factor.get_data() + curr_col_id * stride)
-                .copy(cals::Matrix(copy_factor.get_rows(), 1, copy_factor.get_data() + swap_col_id * stride));
-          curr_col_id++;
-        }
+      for (dim_t n = 0; n < overall.get_n_modes(); n++) {
+        cals::Matrix &f = replica.get_factor(n);
+        cals::Matrix old(f.get_rows(), f.get_cols());
+        old.copy(f);
+        for (dim_t c = 0; c < nc; c++)
+          if ((dim_t)match[c] != c)
+            cals::Matrix(f.get_rows(), 1, f.get_data() + c * f.get_col_stride())
+                .copy(cals::Matrix(old.get_rows(), 1, old.get_data() + (dim_t)match[c] * old.get_col_stride()));
       }
     }
     auto wide = cals::utils::concatenate_ktensors(cals_jk_input[0]);
