@@ -139,6 +139,42 @@ def test_c3_as_benched_vs_oracle(cc, oracle, inputs):
         assert abs(m.error - slow) <= 1e-9 * slow
 
 
+def test_c3_stale_column_patch_equals_dropping_T(cc, inputs):
+    """Config 3 for 40 sweeps (8 line-search rounds, reverts from the second on): keeping a pending T across
+    line-search steps and recomputing only the stale columns (default) gives the models that round 1's
+    rule -- drop T whenever anything changed, CALS_TREE_PATCH_MAX=0 -- gives."""
+    iters = 40
+    ranks = inputs.ranks_1_to_20(256)
+    X = inputs.tensor(MODES, 0)
+    base = inputs.model_factors(MODES, ranks, 1)
+    prm = cc.default_params(max_iterations=iters, force_max_iter=1, line_search=1, line_search_interval=5,
+                            line_search_step=0.0)
+    runs = {}
+    for tag, env in (("patch", None), ("drop", "0")):
+        old = os.environ.get("CALS_TREE_PATCH_MAX")
+        if env is not None:
+            os.environ["CALS_TREE_PATCH_MAX"] = env
+        try:
+            e, gm = _engine(cc, X, base, prm)
+            e.set_profiling(2)
+            rep = e.run()
+            ks = e.kernel_stats()
+            e.close()
+        finally:
+            if env is not None:
+                if old is None:
+                    del os.environ["CALS_TREE_PATCH_MAX"]
+                else:
+                    os.environ["CALS_TREE_PATCH_MAX"] = old
+        runs[tag] = (gm, rep, ks)
+    (gp, rp, kp), (gd, rd, kd) = runs["patch"], runs["drop"]
+    assert (rp.iter, rp.ls_performed, rp.ls_failed) == (rd.iter, rd.ls_performed, rd.ls_failed)
+    assert rp.ls_failed > 0, "the run must contain reverts, or nothing is patched"
+    assert kp.mttkrp_launches > 0 and kd.mttkrp_launches == 0      # the patch path ran / did not run
+    assert kp.ttm_launches < kd.ttm_launches                       # ... and saved whole TTMs
+    _compare(gp, gd)
+
+
 def _c5_models(inputs, world=8, total=2048):
     ranks = [1 + (m % 20) for m in range(total)]
     base = inputs.model_factors(MODES, ranks, 1)
