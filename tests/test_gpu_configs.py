@@ -140,12 +140,14 @@ def test_c3_as_benched_vs_oracle(cc, oracle, inputs):
 
 
 def test_c3_stale_column_patch_equals_dropping_T(cc, inputs):
-    """Config 3 for 40 sweeps (8 line-search rounds, reverts from the second on): keeping a pending T across
+    """Config 3's shape and models for 40 sweeps (8 line-search rounds): keeping a pending T across
     line-search steps and recomputing only the stale columns (default) gives the models that round 1's
     rule -- drop T whenever anything changed, CALS_TREE_PATCH_MAX=0 -- gives."""
     iters = 40
     ranks = inputs.ranks_1_to_20(256)
-    X = inputs.tensor(MODES, 0)
+    # a tensor with structure (rank 6 + noise), so that models converge and extrapolations start to fail
+    # within 40 sweeps (on pure noise the first reverts come after a few hundred sweeps)
+    X = inputs.low_rank_tensor(MODES, 6, seed=11)[0] + 0.05 * inputs.tensor(MODES, 0)
     base = inputs.model_factors(MODES, ranks, 1)
     prm = cc.default_params(max_iterations=iters, force_max_iter=1, line_search=1, line_search_interval=5,
                             line_search_step=0.0)
