@@ -499,27 +499,43 @@ __device__ __attribute__((noinline)) void update_body_lds(const UpdateArgs &a, i
 #pragma unroll
     for (int c = 0; c < RMAX; ++c) Lr[c] = (c < r) ? Hs[li + RMAX * c] : 0.0;
     int info = 0;
+    // RIGHT-looking form of the same factorisation: as soon as column j is final, every later column k
+    // of the row takes its term  A[i][k] -= L[i][j] L[k][j]  -- the terms of an entry still arrive in the
+    // order j = 0, 1, ... with the same operands as in dpotf2's left-looking sum, so the result is the same
+    // to the bit, but the r - j - 1 updates of a column step are independent of each other (the left-looking
+    // form chained j dependent FMAs in front of every pivot).  L[k][j] comes from lane k by v_readlane.
+    // The pivot costs one 1/sqrt: l_jj = a * y, column = s * y with y = 1/sqrt(a) from v_rsq_f64 + two
+    // Newton steps and a final correction of l_jj (the IEEE sqrt followed by an IEEE divide was half of
+    // this phase: 20 dependent ~400-cycle sequences at rank 20).  Entries differ from sqrt / divide by at
+    // most an ulp or two -- far inside the 1e-12 the kernel tests hold against the oracle.
 #pragma unroll
     for (int j = 0; j < RMAX; ++j) {
       if (j < r && info == 0) {
-        double sv = Lr[j];
-#pragma unroll
-        for (int k = 0; k < j; ++k) {
-          const double ljk = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(Lr[k]), j),
-                                              __builtin_amdgcn_readlane(__double2loint(Lr[k]), j));
-          sv -= Lr[k] * ljk;
-        }
-        const double ajj = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(sv), j),
-                                            __builtin_amdgcn_readlane(__double2loint(sv), j));
+        const double ajj = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(Lr[j]), j),
+                                            __builtin_amdgcn_readlane(__double2loint(Lr[j]), j));
         if (!(ajj > 0.0)) {
-          if (lane == j) Lr[j] = ajj;
-          info = j + 1;
+          info = j + 1;  // lane j keeps a_jj in Lr[j], as dpotf2 leaves it
         } else {
+#if CALS_CHOL_EXACT
           const double ljj = sqrt(ajj);
-          if (lane == j)
-            Lr[j] = ljj;
-          else if (lane > j)
-            Lr[j] = sv / ljj;
+          const double cj = Lr[j] / ljj;
+#else
+          double y = __builtin_amdgcn_rsq(ajj);
+          y = y * fma(-0.5 * ajj * y, y, 1.5);
+          y = y * fma(-0.5 * ajj * y, y, 1.5);
+          double ljj = ajj * y;
+          ljj = fma(0.5 * y, fma(-ljj, ljj, ajj), ljj);
+          const double cj = Lr[j] * y;
+#endif
+          Lr[j] = (lane == j) ? ljj : ((lane > j) ? cj : Lr[j]);
+#pragma unroll
+          for (int k = j + 1; k < RMAX; ++k) {
+            if (k < r) {
+              const double lkj = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(Lr[j]), k),
+                                                  __builtin_amdgcn_readlane(__double2loint(Lr[j]), k));
+              Lr[k] -= Lr[j] * lkj;
+            }
+          }
         }
       }
     }
