@@ -471,12 +471,19 @@ __device__ __attribute__((noinline)) void update_body_lds(const UpdateArgs &a, i
   T *xs = reinterpret_cast<T *>(upd_dyn);  // I x r panel, ld = xld (storage type, like the factor)
 
   UPD_STAMP(0);
-  // H = hadamard of the other modes' Gramians (hadamard_but_one)
-  for (int e = tid; e < r * r; e += UPD_THREADS) {
-    const int i = e % r, j = e / r;
-    double h = 1.0;
-    for (int m = 0; m < a.n_modes; ++m)
-      if (m != a.mode) h *= a.gram[m][i + CALS_GLD * (long long)(col + j)];
+  // H = hadamard of the other modes' Gramians (hadamard_but_one), PADDED to RMAX x RMAX with the identity:
+  // the factorisation below then runs over RMAX columns without a single `c < r` guard (r reaches this
+  // non-inlined function in a VGPR, so every guard is an exec-mask save / restore + branch around one FMA).
+  // The padding contributes exact zeros: L comes out as diag(L_r, I).  (The row solves keep their guards:
+  // without them the allocator spills x[] -- measured 11.2 K -> 15.7 K cycles per pass at rank 20.)
+  for (int e = tid; e < RMAX * RMAX; e += UPD_THREADS) {
+    const int i = e % RMAX, j = e / RMAX;
+    double h = (i == j) ? 1.0 : 0.0;
+    if (i < r && j < r) {
+      h = 1.0;
+      for (int m = 0; m < a.n_modes; ++m)
+        if (m != a.mode) h *= a.gram[m][i + CALS_GLD * (long long)(col + j)];
+    }
     Hs[i + RMAX * j] = h;
   }
   __syncthreads();
@@ -495,26 +502,25 @@ __device__ __attribute__((noinline)) void update_body_lds(const UpdateArgs &a, i
   // only logs).
   if (wave == 0 && !solved) {
     double Lr[RMAX];
-    const int li = lane < r ? lane : 0;
+    const int li = lane < RMAX ? lane : 0;
 #pragma unroll
-    for (int c = 0; c < RMAX; ++c) Lr[c] = (c < r) ? Hs[li + RMAX * c] : 0.0;
+    for (int c = 0; c < RMAX; ++c) Lr[c] = Hs[li + RMAX * c];
     int info = 0;
     // RIGHT-looking form of the same factorisation: as soon as column j is final, every later column k
     // of the row takes its term  A[i][k] -= L[i][j] L[k][j]  -- the terms of an entry still arrive in the
-    // order j = 0, 1, ... with the same operands as in dpotf2's left-looking sum, so the result is the same
-    // to the bit, but the r - j - 1 updates of a column step are independent of each other (the left-looking
-    // form chained j dependent FMAs in front of every pivot).  L[k][j] comes from lane k by v_readlane.
+    // order j = 0, 1, ... with the same operands as in dpotf2's left-looking sum, but the RMAX - j - 1
+    // updates of a column step are independent of each other (the left-looking form chained j dependent
+    // FMAs in front of every pivot).  L[k][j] comes from lane k by v_readlane.
     // The pivot costs one 1/sqrt: l_jj = a * y, column = s * y with y = 1/sqrt(a) from v_rsq_f64 + two
-    // Newton steps and a final correction of l_jj (the IEEE sqrt followed by an IEEE divide was half of
-    // this phase: 20 dependent ~400-cycle sequences at rank 20).  Entries differ from sqrt / divide by at
-    // most an ulp or two -- far inside the 1e-12 the kernel tests hold against the oracle.
+    // Newton steps and a final correction of l_jj.  Entries differ from IEEE sqrt / divide by at most an
+    // ulp or two -- far inside the 1e-12 the kernel tests hold against the oracle.
 #pragma unroll
     for (int j = 0; j < RMAX; ++j) {
-      if (j < r && info == 0) {
+      if (info == 0) {
         const double ajj = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(Lr[j]), j),
                                             __builtin_amdgcn_readlane(__double2loint(Lr[j]), j));
         if (!(ajj > 0.0)) {
-          info = j + 1;  // lane j keeps a_jj in Lr[j], as dpotf2 leaves it
+          info = j + 1;  // lane j keeps a_jj in Lr[j], as dpotf2 leaves it (only a real column can fail)
         } else {
 #if CALS_CHOL_EXACT
           const double ljj = sqrt(ajj);
@@ -530,23 +536,21 @@ __device__ __attribute__((noinline)) void update_body_lds(const UpdateArgs &a, i
           Lr[j] = (lane == j) ? ljj : ((lane > j) ? cj : Lr[j]);
 #pragma unroll
           for (int k = j + 1; k < RMAX; ++k) {
-            if (k < r) {
-              const double lkj = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(Lr[j]), k),
-                                                  __builtin_amdgcn_readlane(__double2loint(Lr[j]), k));
-              Lr[k] -= Lr[j] * lkj;
-            }
+            const double lkj = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(Lr[j]), k),
+                                                __builtin_amdgcn_readlane(__double2loint(Lr[j]), k));
+            Lr[k] -= Lr[j] * lkj;
           }
         }
       }
     }
-    if (lane < r) {
+    if (lane < RMAX) {
 #pragma unroll
       for (int c = 0; c < RMAX; ++c)
-        if (c <= lane && c < r) Hs[lane + RMAX * c] = Lr[c];
+        if (c <= lane) Hs[lane + RMAX * c] = Lr[c];
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    if (lane < r) sh.dinv[lane] = 1.0 / Hs[lane + RMAX * lane];
+    if (lane < RMAX) sh.dinv[lane] = 1.0 / Hs[lane + RMAX * lane];
     if (lane == 0) a.mt.potrf_info[slot] = info;
   }
   __syncthreads();
