@@ -1,7 +1,8 @@
-"""BASELINE.json configs 2, 3 and 5 exercised AS CONFIGURED, through the C ABI (cals_hip_run)
-(config 1 = __graft_entry__.smoke() and tests/golden/c1_20cube.npz; config 4 = tests/test_gpu_fp32.py):
+"""BASELINE.json configs 2, 3, 4 and 5 exercised AS CONFIGURED, through the C ABI (cals_hip_run)
+(config 1 = __graft_entry__.smoke() and tests/golden/c1_20cube.npz):
 
   C2  100^3 fp64, 64 models, line search off, 50 forced sweeps, against the oracle.
+  C4  299 x 301 x 41, fp32 storage, 512 models, 10 forced sweeps, against the fp64 oracle (1e-3).
 
   C3  300^3 fp64, 256 models of rank 1 + (m mod 20) (R = 2656), line search NO_ERROR_CHECKING
       interval 5 step cbrt(iter), plan M (multi-sweep dimension tree) -- exactly what bench.py times --
@@ -93,6 +94,42 @@ def test_c2_as_configured_vs_oracle(cc, oracle, inputs):
         oracle.set_threads(1)
     assert orep.iter == iters
     _compare(gm, om)
+
+
+def test_c4_as_configured_vs_fp64_oracle(cc, oracle, inputs):
+    """BASELINE config 4: 299 x 301 x 41 (eemdata-shaped), fp32 storage + fp32 MFMA, 512 models of rank
+    1 + (m mod 20) (R = 5328), 10 forced sweeps, against the fp64 oracle.  Stated tolerance for fp32 storage
+    ("expect 1e-4 ... 1e-3 after 10 sweeps"): factors 1e-3 relative Frobenius, fit 1e-4."""
+    modes, iters = [299, 301, 41], 10
+    ranks = inputs.ranks_1_to_20(512)
+    X = inputs.tensor(modes, 0)
+    base = inputs.model_factors(modes, ranks, 1)
+    e = cc.Engine(modes, sum(ranks), dtype="f32")
+    assert e.tree == 2, "plan B for this shape (what bench.py --workload c4 times)"
+    e.set_tensor(X)
+    e.set_params(cc.default_params(max_iterations=iters, force_max_iter=1))
+    gm = [cc.Model([f.copy() for f in fs], lam.copy()) for fs, lam in base]
+    for m in gm:
+        e.enqueue(m)
+    rep = e.run()
+    e.close()
+    assert rep.iter == iters and rep.ktensor_comp_sum == 5328
+    th = _threads()
+    oracle.use_mkl(th)
+    oracle.set_threads(th)
+    try:
+        om = [oracle.Model([f.copy() for f in fs], lam.copy()) for fs, lam in base]
+        oracle.cp_cals(X, modes, om, oracle.default_params(
+            max_iterations=iters, force_max_iter=1, buffer_size=sum(ranks), mttkrp_method=oracle.MTTKRP, threads=th))
+    finally:
+        oracle.use_own_gemm()
+        oracle.set_threads(1)
+    worst = 0.0
+    for g, o in zip(gm, om):
+        assert g.iters == o.iters
+        worst = max(worst, max(rel(fa, fb) for fa, fb in zip(g.factors, o.factors)))
+        assert abs(g.fit - o.fit) <= 1e-4
+    assert worst < 1e-3, worst
 
 
 def test_c3_as_benched_vs_oracle(cc, oracle, inputs):
