@@ -82,3 +82,36 @@ def test_work_queue_two_ranks_equal_single_model_als(oracle, inputs):
         assert it == m.iters
         d = np.linalg.norm(reconstruct(gf, gl, MODES) - reconstruct(m.factors, m.lam, MODES))
         assert d <= 1e-8 * np.linalg.norm(X)
+
+
+def _rccl_single_rank_worker(port, q):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    t = torch.tensor([3.5], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    parts = [torch.zeros_like(t)]
+    dist.all_gather(parts, t)
+    dist.barrier()
+    q.put((dist.get_backend(), dist.get_world_size(), float(t.item()), float(parts[0].item())))
+    dist.destroy_process_group()
+
+
+def test_rccl_collectives_of_the_bench_load_and_run_on_this_box():
+    """bench.py's control plane for N > 1 is RCCL (backend "nccl"): barrier, all_reduce(MAX / SUM) and
+    all_gather of one float64.  A one-GPU box cannot host two RCCL ranks ("Duplicate GPU detected"), but a
+    single-rank group runs the same library calls on the same dtypes -- enough to know the backend is usable
+    before the driver's 8-GPU run.  (The N > 1 logic itself: tests/test_sharding_gloo.py, and the two-rank
+    gloo rehearsal on this GPU above.)"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_single_rank_worker, args=(_free_port(), q))
+    p.start()
+    backend, world, red, gathered = q.get(timeout=300)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    assert (backend, world, red, gathered) == ("nccl", 1, 3.5, 3.5)
