@@ -11,6 +11,10 @@
  * pinned against the reference's OWN TEST SUITE restated on it (tests/test_oracle_reference_suite.py:
  * tests/als/test_als.cpp and tests/cals/test_cals.cpp of the reference), NOT against outputs of
  * the reference run here: "parity unpinned" with respect to reference-produced numbers.
+ * One exception: the reference's extern/rectangular_lsap/rectangular_lsap.cpp is self-contained, so
+ * oracle/Makefile compiles it from where it lies into oracle/_ref/librectangular_lsap.so, and the
+ * assignment step of the jackknife post-processing (or_jk_permutation_adjust, and the product's own
+ * solver) IS pinned against that build (tests/test_lsap_and_jk_permutation.py).
  *
  * Every function cites the reference file:line (relative to /root/reference) it follows.
  * BLAS/LAPACK are third-party to the reference (MKL 2021.4 / OpenBLAS in its CI); their
