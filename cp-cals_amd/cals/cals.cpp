@@ -28,7 +28,7 @@ struct DeviceMirror {
     int device{0};
     int dtype{0};
     const double *data{nullptr};
-    std::array<double, 34> print{};  // sampled fingerprint of X at upload time
+    std::array<double, 1026> print{};  // sampled fingerprint of X at upload time
     bool busy{false};
   };
   std::mutex mu;
@@ -46,13 +46,17 @@ namespace {
                            "): " + (e ? cals_hip_last_error(e) : "no engine"));
 }
 
-std::array<double, 34> fingerprint(const Tensor &X) {
-  std::array<double, 34> f{};
+// 1024 evenly spaced elements + the size + the middle one.  Not a checksum (that would cost what the upload
+// costs): it catches a Tensor that was refilled / rescaled / swapped behind its mirror, not a single edited
+// element -- for that the caller says invalidate_device_mirror() (the reference's own device copy,
+// include/tensor.h:56-59, is never refreshed at all).
+std::array<double, 1026> fingerprint(const Tensor &X) {
+  std::array<double, 1026> f{};
   const dim_t n = X.get_n_elements();
   if (n == 0) return f;
-  for (dim_t k = 0; k < 32; k++) f[k] = X[(n - 1) * k / 31];
-  f[32] = (double)n;
-  f[33] = X[n / 2];
+  for (dim_t k = 0; k < 1024; k++) f[k] = X[(dim_t)((long double)(n - 1) * k / 1023)];
+  f[1024] = (double)n;
+  f[1025] = X[n / 2];
   return f;
 }
 
