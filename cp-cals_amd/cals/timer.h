@@ -20,26 +20,27 @@ class Timer {
   [[nodiscard]] double get_time() const { return seconds < 0.0 ? 0.0 : seconds; }
 };
 
-// include/timer.h:29-52.  On the device engine the slots are filled from hipEvent pairs / the loop's host
+// The three timer families of include/timer.h:29-52: a Timer per slot, the slot names label the CSV columns
+// of CalsReport / AlsReport.  On the device engine the slots are filled from hipEvent pairs / the loop's host
 // clock (cals_hip_sweep_record): MT_GEMM = the fused MTTKRP kernel, TS_GEMM = the TTM of a dimension-tree
 // pair, TS_GEMV = the contraction of T, MT_KRP = the Khatri-Rao kernel of N > 3 modes.
-struct MttkrpTimers {
+template <int N>
+struct TimerSet {
+  std::string names[N];
+  Timer timers[N];
+  Timer &operator[](int slot) { return timers[slot]; }
+};
+struct MttkrpTimers : TimerSet<4> {
   enum TIMERS { MT_KRP = 0, MT_GEMM, TS_GEMM, TS_GEMV, LENGTH };
-  std::string names[LENGTH] = {"MT_KRP", "MT_GEMM", "TS_GEMM", "TS_GEMV"};
-  Timer timers[LENGTH];
-  Timer &operator[](int t) { return timers[t]; }
+  MttkrpTimers() : TimerSet<4>{{"MT_KRP", "MT_GEMM", "TS_GEMM", "TS_GEMV"}, {}} {}
 };
-struct ModeTimers {
+struct ModeTimers : TimerSet<2> {
   enum TIMERS { MTTKRP = 0, UPDATE, LENGTH };
-  std::string names[LENGTH] = {"TOTAL_MTTKRP", "UPDATE"};
-  Timer timers[LENGTH];
-  Timer &operator[](int t) { return timers[t]; }
+  ModeTimers() : TimerSet<2>{{"TOTAL_MTTKRP", "UPDATE"}, {}} {}
 };
-struct AlsTimers {
+struct AlsTimers : TimerSet<5> {
   enum TIMERS { ITERATION = 0, DEFRAGMENTATION, ERROR, LINE_SEARCH, G_COPY, LENGTH };
-  std::string names[LENGTH] = {"ITERATION", "DEFRAGMENTATION", "ERROR", "LINESEARCH", "G_COPY"};
-  Timer timers[LENGTH];
-  Timer &operator[](int t) { return timers[t]; }
+  AlsTimers() : TimerSet<5>{{"ITERATION", "DEFRAGMENTATION", "ERROR", "LINESEARCH", "G_COPY"}, {}} {}
 };
 }  // namespace cals
 #endif
