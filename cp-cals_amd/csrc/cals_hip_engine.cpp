@@ -142,6 +142,8 @@ struct cals_hip_engine {
   size_t partial_elems = 0;
   double *hscratch = nullptr;  // models of rank > CALS_RMAX: H / L blocks of update_body_huge
   size_t hscratch_blocks = 0;
+  double *nnls_hscratch = nullptr;  // ... and the blocks of nnls_huge_kernel
+  size_t nnls_hblocks = 0;
   int *d_hcounter = nullptr;
   void *krp_ws = nullptr;
   size_t krp_elems = 0;
@@ -763,9 +765,18 @@ int sweep_once(cals_hip_engine *e, bool evict_enabled, bool defer_changed = fals
     if (e->models[t].rank > CALS_RMAX) n_huge++;
   }
   if (n_huge) {
-    if (e->prm.update_method == 1)
-      return fail(e, CALS_HIP_ERR_ARG, "models of rank > 64 support the unconstrained update only (the NNLS "
-                                       "kernel keeps a row's active set in one 64-bit mask)");
+    if (e->prm.update_method == 1) {  // nnls_huge_kernel: H and the waves' Cholesky factors, per workgroup
+      int chunks = 1;
+      for (int n = 0; n < e->n_modes; n++) chunks = std::max(chunks, nnls_huge_chunks((int)e->modes[n]));
+      const size_t need = n_huge * (size_t)chunks;
+      if (need > e->nnls_hblocks) {
+        if (e->nnls_hscratch) HIPCHK(hipFree(e->nnls_hscratch));
+        e->nnls_hscratch = nullptr;
+        e->nnls_hblocks = 0;
+        HIPCHK(hipMalloc((void **)&e->nnls_hscratch, need * nnls_huge_block_doubles() * sizeof(double)));
+        e->nnls_hblocks = need;
+      }
+    }
     if (e->prm.line_search && e->prm.line_search_method != 0) n_huge *= 2;  // H and one Gramian at a time
     if (n_huge > e->hscratch_blocks) {
       if (e->hscratch) HIPCHK(hipFree(e->hscratch));
@@ -840,7 +851,10 @@ int sweep_once(cals_hip_engine *e, bool evict_enabled, bool defer_changed = fals
       q.rowdot = e->rowdot;
       q.status = e->d_nnls_status;
       q.rmax = rank_max;
+      q.hscratch = e->nnls_hscratch;
+      q.hcounter = e->d_hcounter;
       HIPCHK(nnls_launch(q, e->stream));
+      if (n_huge) HIPCHK(hipMemsetAsync(e->d_hcounter, 0, sizeof(int), e->stream));
       u.rowdot = e->rowdot;
     }
     HIPCHK(update_launch(u, rank_max, e->stream));
@@ -1126,7 +1140,7 @@ int compress(cals_hip_engine *e) {
         add(e->prev[n], e->modes[n], wpe);
         add(e->backup[n], e->modes[n], wpe);
       }
-      // the active sets of a model sit in its first column (64-bit words; the other columns are unused)
+      // the active sets of a model sit in its first (rank + 63) / 64 columns (64-bit words; the rest is unused)
       if (e->nnls_allocated) add(e->act[n], e->modes[n], 2);
       if (e->nnls_ls_allocated) add(e->act_backup[n], e->modes[n], 2);
     }
@@ -1647,6 +1661,7 @@ int cals_hip_destroy(cals_hip_engine *e) {
   if (e->ev_out) (void)hipEventDestroy(e->ev_out);
   fr(e->partial);
   fr(e->hscratch);
+  fr(e->nnls_hscratch);
   fr(e->d_hcounter);
   fr(e->tree.Tbuf);
   fr(e->tree.Pt);

@@ -169,14 +169,19 @@ struct NnlsArgs {
   int I;
   double *gram[CALS_MAX_MODES];
   int n_modes, mode;
-  unsigned long long *act;  // Ktensor::active_set of this mode: [I x buffer], the mask of (row, model)
-                            // at row + I * col(model); bit i set = constraint i active
+  unsigned long long *act;  // Ktensor::active_set of this mode: [I x buffer]; word q of (row, model) -- the
+                            // constraints of components 64 q .. 64 q + 63, bit set = active -- at
+                            // row + I * (col(model) + q)
   double *rowdot;      // out: [n_slots][I]
   int *status;         // sticky OR: 1 Cholesky failure in the main loop, 2 exchange bound reached
   int rmax;            // largest rank in flight (sizes the LDS tiles)
   int chunks;          // set by nnls_launch: workgroups per model
+  double *hscratch;    // models above CALS_RMAX: n_huge * nnls_huge_chunks(I) blocks of nnls_huge_block_doubles()
+  int *hcounter;       // zero at launch: blocks are handed out in arrival order
 };
 hipError_t nnls_launch(const NnlsArgs &a, hipStream_t st);
+size_t nnls_huge_block_doubles();
+int nnls_huge_chunks(int I);
 struct NnlsResetArgs {
   unsigned long long *act[CALS_MAX_MODES];
   int I[CALS_MAX_MODES];

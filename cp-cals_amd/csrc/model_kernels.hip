@@ -983,8 +983,8 @@ __device__ __attribute__((noinline)) void update_body_big(const UpdateArgs &a, i
 // broadcast loads).  Same operations as update_body_big -- unblocked Cholesky in dpotf2's order, dtrsm
 // Right/Lower/Trans then Right/Lower/NoTrans row by row, |L^-1 g_i|^2 for the error term -- with the whole
 // workgroup on the factorisation (lane = row no longer fits one wave).  Built to be right, not fast: the
-// reference's typical ranks are <= 20 and everything up to 64 runs the bodies above.  The NNLS update stays
-// limited to CALS_RMAX (the engine rejects the combination).
+// reference's typical ranks are <= 20 and everything up to 64 runs the bodies above.  After the NNLS update
+// (a.rowdot, nnls_huge_kernel) the panel already holds the solution and only the tail runs.
 template <typename T>
 __device__ __attribute__((noinline)) void update_body_huge(const UpdateArgs &a, int slot, int r,
                                                            UpdShared &sh) {
@@ -999,11 +999,13 @@ __device__ __attribute__((noinline)) void update_body_huge(const UpdateArgs &a, 
   __shared__ int s_info, s_block;
   // scratch blocks are handed out in arrival order (the engine sizes the pool by the number of such models
   // in flight and zeroes the counter before the launch)
-  if (tid == 0) s_block = atomicAdd(a.hcounter, 1);
+  const double *rowdot = a.rowdot ? a.rowdot + (long long)I * blockIdx.x : nullptr;
+  const bool solved = rowdot != nullptr;
+  if (tid == 0) s_block = solved ? 0 : atomicAdd(a.hcounter, 1);
   __syncthreads();
   double *H = a.hscratch + (long long)s_block * LD * LD;  // r x r, ld LD
 
-  for (int e = tid; e < r * r; e += UPD_THREADS) {
+  for (int e = tid; e < (solved ? 0 : r * r); e += UPD_THREADS) {
     const int i = e % r, j = e / r;
     double h = 1.0;
     for (int m = 0; m < a.n_modes; ++m)
@@ -1014,7 +1016,7 @@ __device__ __attribute__((noinline)) void update_body_huge(const UpdateArgs &a, 
   __threadfence_block();
   __syncthreads();
   // dpotf2, column j: s_i = H[i][j] - sum_{k<j} L[i][k] L[j][k] for the rows i >= j, one row per thread
-  for (int j = 0; j < r; ++j) {
+  for (int j = 0; j < (solved ? 0 : r); ++j) {
     double sv[(CALS_GLD + UPD_THREADS - 1) / UPD_THREADS];
 #pragma unroll
     for (int q = 0; q < (CALS_GLD + UPD_THREADS - 1) / UPD_THREADS; ++q) {
@@ -1049,7 +1051,8 @@ __device__ __attribute__((noinline)) void update_body_huge(const UpdateArgs &a, 
     __syncthreads();
   }
   __syncthreads();
-  for (int k = tid; k < r; k += UPD_THREADS) sh.dinv[k] = 1.0 / H[k + LD * k];
+  if (!solved)
+    for (int k = tid; k < r; k += UPD_THREADS) sh.dinv[k] = 1.0 / H[k + LD * k];
   if (tid == 0) a.mt.potrf_info[slot] = s_info;
   __threadfence_block();
   __syncthreads();
@@ -1060,6 +1063,13 @@ __device__ __attribute__((noinline)) void update_body_huge(const UpdateArgs &a, 
   double t3 = 0.0;
   for (int i = tid; i < I; i += UPD_THREADS) {
     T *x = fac + i;  // row i: x[c] at x[I * c]
+    if (solved) {
+      if (i != jkf)
+        t3 += rowdot[i];
+      else
+        for (int c = 0; c < r; ++c) x[(long long)I * c] = (T)((double)x[(long long)I * c] * 0.0);
+      continue;
+    }
     // B := B * inv(L^T): forward substitution along the row
     for (int k = 0; k < r; ++k) {
       const double xk = dinv[k] * (double)x[(long long)I * k];
@@ -1480,9 +1490,10 @@ __global__ void __launch_bounds__(256) ls_kernel(const LsArgs a) {
       }
       if (tid < r) a.lambda[col + tid] = a.backup_lambda[col + tid];
       for (int m = 0; m < a.n_modes; ++m)
-        if (a.act[m])
-          for (int i = tid; i < a.I[m]; i += 256)
-            a.act[m][i + (long long)a.I[m] * col] = a.act_backup[m][i + (long long)a.I[m] * col];
+        if (a.act[m]) {  // (r + 63) / 64 mask words per row, word q in column col + q
+          const long long n = (long long)a.I[m] * ((r + 63) >> 6), off = (long long)a.I[m] * col;
+          for (long long e = tid; e < n; e += 256) a.act[m][off + e] = a.act_backup[m][off + e];
+        }
       regram = true;
     }
   }
@@ -1511,9 +1522,10 @@ __global__ void __launch_bounds__(256) ls_kernel(const LsArgs a) {
     }
     if (tid < r) a.backup_lambda[col + tid] = a.lambda[col + tid];
     for (int m = 0; m < a.n_modes; ++m)
-      if (a.act[m])
-        for (int i = tid; i < a.I[m]; i += 256)
-          a.act_backup[m][i + (long long)a.I[m] * col] = a.act[m][i + (long long)a.I[m] * col];
+      if (a.act[m]) {
+        const long long n = (long long)a.I[m] * ((r + 63) >> 6), off = (long long)a.I[m] * col;
+        for (long long e = tid; e < n; e += 256) a.act_backup[m][off + e] = a.act[m][off + e];
+      }
     if (tid == 0) {
       a.mt.bk_err[slot] = a.mt.err[slot];
       a.mt.bk_fit[slot] = a.mt.fit[slot];

@@ -3,7 +3,8 @@
 //
 // The reference runs, for every row of a model's factor, an active-set NNLS (fast NNLS of Bro & de
 // Jong, warm-started from the passive set the row had in the previous sweep): a handful of
-// dposv solves on sub-matrices G[P,P] of the r x r Hadamard product H, r <= 64.  Rows are
+// dposv solves on sub-matrices G[P,P] of the r x r Hadamard product H (r <= 64 here; nnls_huge_kernel at
+// the end of the file takes the ranks above).  Rows are
 // independent, the solves are tiny and latency bound, and every row follows its own sequence of
 // passive sets.  Mapping here: ONE WAVEFRONT PER ROW, lane i = component i.
 //   * the active set is a 64-bit mask in scalar registers (ballots), so the whole control flow of
@@ -189,6 +190,7 @@ __global__ void __launch_bounds__(256) nnls_kernel(const NnlsArgs a) {
   const int k_model = blockIdx.x / a.chunks, chunk = blockIdx.x % a.chunks;
   const int slot = a.slots[k_model];
   const int r = a.mt.rank[slot], col = a.mt.col[slot];
+  if (r > CALS_RMAX) return;  // nnls_huge_kernel's share
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int W = blockDim.x >> 6;
   const int I = a.I;
@@ -330,6 +332,381 @@ __global__ void __launch_bounds__(256) nnls_kernel(const NnlsArgs a) {
   if (status && lane == 0) atomicOr(a.status, status);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Ranks 65..CALS_GLD.  Same algorithm, same operation order, one wavefront per row -- but a row has up to
+// four components per lane (component c = lane + 64 q), the active set is NNLS_HQ 64-bit words (word q of
+// (row, model) at act[row + I * (col + q)]: a model owns r >= 64 q columns of that buffer), and neither H
+// nor a Cholesky factor of up to 256 x 256 fits LDS: H (one copy per workgroup) and each wave's factor
+// live in a global scratch block (L2 resident), the factor twice -- column-contiguous (Lt) for the
+// factorisation and the forward substitution, row-contiguous (Lr) for the back substitution -- so that
+// every load a wave issues is one coalesced line per 8 lanes.  The compacted right-hand side, the diagonal,
+// d and the index map stay in LDS.  Built to be right, not fast (as update_body_huge): the reference's
+// typical ranks are <= 20.
+#define NNLS_HQ (CALS_GLD / 64)
+#define NNLS_HWAVES 4
+
+namespace {
+
+typedef unsigned long long u64;
+
+struct HugeWave {
+  double *Lt;  // global: L[p][k] at Lt[k * CALS_GLD + p]
+  double *Lr;  // global: L[p][k] at Lr[p * CALS_GLD + k]
+  double *cv, *xs, *dgs, *dv;  // LDS, CALS_GLD each
+  int *idx;                    // LDS
+  u64 cached[NNLS_HQ];
+  bool has_cache;
+};
+
+__device__ __forceinline__ bool any_bits(const u64 (&m)[NNLS_HQ]) {
+  u64 o = 0;
+#pragma unroll
+  for (int q = 0; q < NNLS_HQ; ++q) o |= m[q];
+  return o != 0;
+}
+__device__ __forceinline__ int count_bits(const u64 (&m)[NNLS_HQ]) {
+  int n = 0;
+#pragma unroll
+  for (int q = 0; q < NNLS_HQ; ++q) n += __popcll(m[q]);
+  return n;
+}
+
+// calculate_sp for the passive set pas (np = its size >= 1); see solve_passive
+__device__ bool solve_passive_huge(const double *Hs, int r, HugeWave &ws, const u64 (&pas)[NNLS_HQ], int np,
+                                   const double (&y)[NNLS_HQ], int lane, double (&x)[NNLS_HQ]) {
+  constexpr int LD = CALS_GLD;
+  const u64 below_me = (1ull << lane) - 1ull;
+  {
+    int base = 0;
+#pragma unroll
+    for (int q = 0; q < NNLS_HQ; ++q) {
+      if ((pas[q] >> lane) & 1ull) {
+        const int pos = base + __popcll(pas[q] & below_me);
+        ws.idx[pos] = lane + 64 * q;
+        ws.cv[pos] = y[q];
+      }
+      base += __popcll(pas[q]);
+    }
+  }
+  WAVE_SYNC();
+  const int nq = (np + 63) >> 6;
+  bool same = ws.has_cache;
+#pragma unroll
+  for (int q = 0; q < NNLS_HQ; ++q) same = same && (pas[q] == ws.cached[q]);
+  if (same) {
+    for (int j = 0; j < np; ++j) {  // L z = b with the cached factor, same operation order
+      const double zj = ws.cv[j] / ws.dgs[j];
+      WAVE_SYNC();
+#pragma unroll
+      for (int q = 0; q < NNLS_HQ; ++q) {
+        const int p = lane + 64 * q;
+        if (q < nq) {
+          if (p == j)
+            ws.cv[p] = zj;
+          else if (p < np && p > j)
+            ws.cv[p] -= ws.Lt[(size_t)j * LD + p] * zj;
+        }
+      }
+      WAVE_SYNC();
+    }
+  } else {
+    ws.has_cache = false;
+    for (int j = 0; j < np; ++j) {
+      const int ij = __builtin_amdgcn_readfirstlane(ws.idx[j]);
+      double ajj = Hs[ij + (size_t)r * ij];
+      double sv[NNLS_HQ];
+#pragma unroll
+      for (int q = 0; q < NNLS_HQ; ++q) {
+        const int p = lane + 64 * q;
+        sv[q] = (q < nq && p < np && p > j) ? Hs[ws.idx[p] + (size_t)r * ij] : 0.0;
+      }
+      const double *Ltj = ws.Lt + j, *Ltp = ws.Lt + lane;
+#pragma unroll 2
+      for (int k = 0; k < j; ++k) {  // the subtractions stay in k order; rows outside (j, np) compute unused values
+        const double ljk = Ltj[(size_t)k * LD];
+        ajj -= ljk * ljk;
+#pragma unroll
+        for (int q = 0; q < NNLS_HQ; ++q)
+          if (q < nq) sv[q] -= Ltp[(size_t)k * LD + 64 * q] * ljk;
+      }
+      ajj = first_lane(ajj);
+      if (!(ajj > 0.0)) return false;
+      const double ljj = sqrt(ajj);
+      const double zj = ws.cv[j] / ljj;  // forward substitution, column by column
+      WAVE_SYNC();
+#pragma unroll
+      for (int q = 0; q < NNLS_HQ; ++q) {
+        const int p = lane + 64 * q;
+        if (q < nq) {
+          if (p == j) {
+            ws.cv[p] = zj;
+            ws.dgs[p] = ljj;
+          } else if (p < np && p > j) {
+            const double lij = sv[q] / ljj;
+            ws.Lt[(size_t)j * LD + p] = lij;
+            ws.Lr[(size_t)p * LD + j] = lij;
+            ws.cv[p] -= lij * zj;
+          }
+        }
+      }
+      __threadfence_block();  // column j of the factor is read by the other lanes from the next step on
+      WAVE_SYNC();
+    }
+#pragma unroll
+    for (int q = 0; q < NNLS_HQ; ++q) ws.cached[q] = pas[q];
+    ws.has_cache = true;
+  }
+  for (int j = np - 1; j >= 0; --j) {  // L^T x = z
+    const double xj = ws.cv[j] / ws.dgs[j];
+    WAVE_SYNC();
+#pragma unroll
+    for (int q = 0; q < NNLS_HQ; ++q) {
+      const int p = lane + 64 * q;
+      if (q < nq) {
+        if (p == j)
+          ws.cv[p] = xj;
+        else if (p < j)
+          ws.cv[p] -= ws.Lr[(size_t)j * LD + p] * xj;
+      }
+    }
+    WAVE_SYNC();
+  }
+#pragma unroll
+  for (int q = 0; q < NNLS_HQ; ++q) {
+    const int p = lane + 64 * q;
+    if (q < nq && p < np) ws.xs[ws.idx[p]] = ws.cv[p];
+  }
+  WAVE_SYNC();
+#pragma unroll
+  for (int q = 0; q < NNLS_HQ; ++q) x[q] = ((pas[q] >> lane) & 1ull) ? ws.xs[lane + 64 * q] : 0.0;
+  WAVE_SYNC();  // the next solve rewrites idx / cv / xs
+  return true;
+}
+
+// w = y - G d, dgemv 'N' order (j ascending)
+__device__ __forceinline__ void multipliers_huge(const double *Hs, int r, HugeWave &ws, const double (&y)[NNLS_HQ],
+                                                 const double (&d)[NNLS_HQ], int lane, double (&w)[NNLS_HQ]) {
+#pragma unroll
+  for (int q = 0; q < NNLS_HQ; ++q)
+    if (lane + 64 * q < r) ws.dv[lane + 64 * q] = d[q];
+  WAVE_SYNC();
+  double acc[NNLS_HQ];
+  int row[NNLS_HQ];
+#pragma unroll
+  for (int q = 0; q < NNLS_HQ; ++q) {
+    acc[q] = 0.0;
+    row[q] = (lane + 64 * q < r) ? lane + 64 * q : 0;
+  }
+  for (int j = 0; j < r; ++j) {
+    const double dj = ws.dv[j];
+#pragma unroll
+    for (int q = 0; q < NNLS_HQ; ++q)
+      if (64 * q < r) acc[q] += Hs[row[q] + (size_t)r * j] * dj;
+  }
+#pragma unroll
+  for (int q = 0; q < NNLS_HQ; ++q) w[q] = y[q] - acc[q];
+  WAVE_SYNC();
+}
+
+}  // namespace
+
+size_t nnls_huge_block_doubles() {
+  return (size_t)CALS_GLD * CALS_GLD * (1 + 2 * NNLS_HWAVES);
+}
+int nnls_huge_chunks(int I) { return std::max(1, std::min((I + 4 * NNLS_HWAVES - 1) / (4 * NNLS_HWAVES), 16)); }
+
+template <typename T>
+__global__ void __launch_bounds__(64 * NNLS_HWAVES) nnls_huge_kernel(const NnlsArgs a) {
+  const int k_model = blockIdx.x / a.chunks, chunk = blockIdx.x % a.chunks;
+  const int slot = a.slots[k_model];
+  const int r = a.mt.rank[slot], col = a.mt.col[slot];
+  if (r <= CALS_RMAX) return;  // nnls_kernel's share
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int I = a.I;
+  __shared__ double s_vec[NNLS_HWAVES][4][CALS_GLD];
+  __shared__ int s_idx[NNLS_HWAVES][CALS_GLD];
+  __shared__ int s_block;
+  if (tid == 0) s_block = atomicAdd(a.hcounter, 1);
+  __syncthreads();
+  double *Hs = a.hscratch + (size_t)s_block * ((size_t)CALS_GLD * CALS_GLD * (1 + 2 * NNLS_HWAVES));
+  HugeWave ws;
+  ws.Lt = Hs + (size_t)CALS_GLD * CALS_GLD * (1 + 2 * wave);
+  ws.Lr = ws.Lt + (size_t)CALS_GLD * CALS_GLD;
+  ws.cv = s_vec[wave][0];
+  ws.xs = s_vec[wave][1];
+  ws.dgs = s_vec[wave][2];
+  ws.dv = s_vec[wave][3];
+  ws.idx = s_idx[wave];
+  ws.has_cache = false;
+#pragma unroll
+  for (int q = 0; q < NNLS_HQ; ++q) ws.cached[q] = 0;
+
+  for (int e = tid; e < r * r; e += blockDim.x) {  // hadamard_but_one, ld = r
+    const int i = e % r, j = e / r;
+    double h = 1.0;
+    for (int m = 0; m < a.n_modes; ++m)
+      if (m != a.mode) h *= a.gram[m][i + CALS_GLD * (long long)(col + j)];
+    Hs[i + (size_t)r * j] = h;
+  }
+  __threadfence_block();
+  __syncthreads();
+  double tol;  // 10 eps ||H||_1 n
+  {
+    double cs = -DBL_MAX;
+#pragma unroll
+    for (int q = 0; q < NNLS_HQ; ++q) {
+      const int c = lane + 64 * q;
+      if (c < r) {
+        double s_ = 0.0;
+        for (int i = 0; i < r; ++i) s_ += fabs(Hs[i + (size_t)r * c]);
+        cs = fmax(cs, s_);
+      }
+    }
+    tol = 10 * 2.2204e-16 * wave_max(cs) * (double)r;
+  }
+  u64 rmask[NNLS_HQ];
+  bool in[NNLS_HQ];
+#pragma unroll
+  for (int q = 0; q < NNLS_HQ; ++q) {
+    const int left = r - 64 * q;
+    rmask[q] = left >= 64 ? ~0ull : (left > 0 ? ((1ull << left) - 1ull) : 0ull);
+    in[q] = lane + 64 * q < r;
+  }
+  T *fac = static_cast<T *>(a.factor) + (long long)I * col;
+  u64 *actp = a.act + (long long)I * col;
+  double *rowdot = a.rowdot + (long long)I * k_model;
+  const int rows_per = (I + a.chunks - 1) / a.chunks;
+  const int row0 = chunk * rows_per, row1 = min(I, row0 + rows_per);
+  int status = 0;
+
+#define HQ_FOR _Pragma("unroll") for (int q = 0; q < NNLS_HQ; ++q)
+  for (int row = row0 + wave; row < row1; row += NNLS_HWAVES) {
+    double y[NNLS_HQ], d[NNLS_HQ], sp[NNLS_HQ], w[NNLS_HQ];
+    u64 act[NNLS_HQ], pas[NNLS_HQ];
+    HQ_FOR {
+      y[q] = in[q] ? (double)fac[row + (long long)I * (lane + 64 * q)] : 0.0;
+      d[q] = 0.0;
+      sp[q] = 0.0;
+      act[q] = rmask[q] ? (uniform64(actp[row + (long long)I * q]) & rmask[q]) : 0ull;
+      act[q] &= ~__ballot(in[q] && y[q] > 0.0);  // "determine previous active set"
+      pas[q] = ~act[q] & rmask[q];
+    }
+    int budget = NNLS_MAX_EXCHANGES;
+    // min over the passive entries of sp / over the given per-lane values
+    auto min_passive_sp = [&]() {
+      double v = DBL_MAX;
+      HQ_FOR if ((pas[q] >> lane) & 1ull) v = fmin(v, sp[q]);
+      return wave_min(v);
+    };
+    if (any_bits(pas)) {  // warm start (update.cpp:93-121)
+      bool failed = !solve_passive_huge(Hs, r, ws, pas, count_bits(pas), y, lane, sp);
+      if (!failed) {
+        HQ_FOR d[q] = sp[q];
+        for (;;) {
+          if (!(min_passive_sp() <= tol)) break;
+          HQ_FOR {
+            const bool z = in[q] && d[q] <= tol;
+            if (z) d[q] = 0.0;
+            act[q] |= __ballot(z);
+            pas[q] = ~act[q] & rmask[q];
+          }
+          if (!any_bits(pas)) {  // ZeroPassiveSet
+            failed = true;
+            break;
+          }
+          if (!solve_passive_huge(Hs, r, ws, pas, count_bits(pas), y, lane, sp)) {
+            failed = true;
+            break;
+          }
+          HQ_FOR d[q] = sp[q];
+          if (--budget <= 0) {
+            status |= 2;
+            break;
+          }
+        }
+      }
+      if (failed) {  // the catch block: restart from the all-active set
+        HQ_FOR {
+          act[q] = rmask[q];
+          d[q] = 0.0;
+        }
+      }
+    }
+    multipliers_huge(Hs, r, ws, y, d, lane, w);
+    for (;;) {  // main loop (update.cpp:126-167)
+      if (!any_bits(act) || budget <= 0) break;
+      double wl = -DBL_MAX;
+      HQ_FOR if ((act[q] >> lane) & 1ull) wl = fmax(wl, w[q]);
+      const double wmax = wave_max(wl);
+      if (!(wmax > tol)) break;
+      {  // Tensor::max_id: the first of equal maxima = lowest component = lowest word, then lowest lane
+        bool taken = false;
+        HQ_FOR {
+          const u64 hit = __ballot(((act[q] >> lane) & 1ull) && w[q] == wmax);
+          if (!taken && hit) {
+            act[q] &= ~(1ull << (__ffsll((long long)hit) - 1));
+            taken = true;
+          }
+        }
+      }
+      HQ_FOR pas[q] = ~act[q] & rmask[q];
+      if (!solve_passive_huge(Hs, r, ws, pas, count_bits(pas), y, lane, sp)) {
+        status |= 1;
+        break;
+      }
+      bool stop = false;
+      for (;;) {  // inner loop (update.cpp:136-157)
+        if (!(min_passive_sp() <= tol)) break;
+        double al = DBL_MAX;
+        HQ_FOR if (((pas[q] >> lane) & 1ull) && sp[q] <= tol) al = fmin(al, d[q] / (d[q] - sp[q]));
+        const double alpha = wave_min(al);
+        HQ_FOR {
+          if (in[q]) d[q] = d[q] + alpha * (sp[q] - d[q]);
+          const bool na = ((pas[q] >> lane) & 1ull) && fabs(d[q]) < tol;
+          if (na) d[q] = 0.0;
+          act[q] |= __ballot(na);
+        }
+        HQ_FOR pas[q] = ~act[q] & rmask[q];
+        if (!any_bits(pas)) {
+          status |= 2;
+          stop = true;
+          break;
+        }
+        if (!solve_passive_huge(Hs, r, ws, pas, count_bits(pas), y, lane, sp)) {
+          status |= 1;
+          stop = true;
+          break;
+        }
+        if (--budget <= 0) {
+          status |= 2;
+          break;
+        }
+      }
+      if (stop) break;
+      HQ_FOR d[q] = sp[q];
+      multipliers_huge(Hs, r, ws, y, d, lane, w);
+      if (--budget <= 0) {
+        status |= 2;
+        break;
+      }
+    }
+    double dl = 0.0;
+    HQ_FOR {
+      if (in[q]) {
+        fac[row + (long long)I * (lane + 64 * q)] = (T)d[q];
+        dl += d[q] * y[q];
+      }
+    }
+    const double dot = wave_add(dl);
+    if (lane == 0) {
+      HQ_FOR if (rmask[q]) actp[row + (long long)I * q] = act[q];
+      rowdot[row] = dot;
+    }
+  }
+#undef HQ_FOR
+  if (status && lane == 0) atomicOr(a.status, status);
+}
+
 size_t nnls_lds_bytes(int rmax, int waves) {
   const size_t per_wave = (size_t)rmax * (rmax | 1) + 64 + 64 + 32;
   return ((size_t)rmax * rmax + per_wave * waves) * sizeof(double);
@@ -338,6 +715,8 @@ size_t nnls_lds_bytes(int rmax, int waves) {
 hipError_t nnls_launch(const NnlsArgs &a_in, hipStream_t st) {
   if (a_in.n_slots <= 0) return hipSuccess;
   NnlsArgs a = a_in;
+  const bool huge = a.rmax > CALS_RMAX;
+  if (huge && (!a.hscratch || !a.hcounter)) return hipErrorInvalidValue;
   a.rmax = std::min(std::max(a.rmax, 1), CALS_RMAX);
   const size_t budget = (size_t)160 * 1024 - 1024;
   int waves = 4;
@@ -358,6 +737,14 @@ hipError_t nnls_launch(const NnlsArgs &a_in, hipStream_t st) {
     hipLaunchKernelGGL(nnls_kernel<float>, grid, block, dyn, st, a);
   else
     hipLaunchKernelGGL(nnls_kernel<double>, grid, block, dyn, st, a);
+  if (huge) {  // the models above CALS_RMAX; every other workgroup returns at once
+    a.chunks = nnls_huge_chunks(a.I);
+    const dim3 hgrid((unsigned)(a.n_slots * a.chunks)), hblock(64 * NNLS_HWAVES);
+    if (di)
+      hipLaunchKernelGGL(nnls_huge_kernel<float>, hgrid, hblock, 0, st, a);
+    else
+      hipLaunchKernelGGL(nnls_huge_kernel<double>, hgrid, hblock, 0, st, a);
+  }
   return hipGetLastError();
 }
 
@@ -365,10 +752,13 @@ hipError_t nnls_launch(const NnlsArgs &a_in, hipStream_t st) {
 // desc as for init_slots_launch: n x {slot, col, rank, jk_mode, jk_fiber}
 __global__ void __launch_bounds__(256) nnls_reset_kernel(const int *desc, NnlsResetArgs a) {
   const int col = desc[5 * blockIdx.x + 1], r = desc[5 * blockIdx.x + 2];
-  const unsigned long long rmask = (r >= 64) ? ~0ull : ((1ull << r) - 1ull);
-  for (int m = 0; m < a.n_modes; ++m) {
-    unsigned long long *p = a.act[m] + (long long)a.I[m] * col;
-    for (int i = threadIdx.x; i < a.I[m]; i += 256) p[i] = rmask;
+  for (int q = 0; 64 * q < r; ++q) {  // word q of a row: components 64 q .. 64 q + 63
+    const int left = r - 64 * q;
+    const unsigned long long rmask = (left >= 64) ? ~0ull : ((1ull << left) - 1ull);
+    for (int m = 0; m < a.n_modes; ++m) {
+      unsigned long long *p = a.act[m] + (long long)a.I[m] * (col + q);
+      for (int i = threadIdx.x; i < a.I[m]; i += 256) p[i] = rmask;
+    }
   }
 }
 

@@ -22,7 +22,7 @@ extern "C" {
 #define CALS_HIP_MAX_MODES 8
 #define CALS_HIP_MAX_RANK 256 /* per-model rank limit.  Ranks 1..32: register / LDS update bodies; 33..64: H in
                                * LDS, rows in registers; 65..256: H and the row solves through global memory
-                               * (unconstrained update only: NNLS keeps a row's active set in one 64-bit mask) */
+                               * (both update methods; the NNLS active set of a row is (rank + 63) / 64 words) */
 
 /* status codes */
 enum {

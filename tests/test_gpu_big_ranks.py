@@ -1,8 +1,8 @@
 """Models of rank 65..256 (the reference is unbounded, include/ktensor.h; round 1 stopped at 64):
 update_body_huge keeps H / L in a global scratch block per model and solves every factor row in place.
 Same oracle, same tolerances as the other bodies; mixed with small models in one buffer, queued,
-jackknifed, with both line-search methods, under every MTTKRP plan, in fp32 storage.  NNLS stays limited to
-rank 64 (64-bit active-set masks) and says so."""
+jackknifed, with both line-search methods, under every MTTKRP plan, in fp32 storage, and with the NNLS update
+(nnls_huge_kernel: (rank + 63) / 64 active-set words per row, H and the Cholesky factors in global scratch)."""
 import os
 
 import numpy as np
@@ -112,19 +112,70 @@ def test_error_checking_line_search(cc, oracle, inputs):
     _assert_models_match(gm, om, ro.X_norm ** 2, tol=1e-7)
 
 
-def test_unsupported_combinations_fail_loudly(cc, inputs):
+def _nonneg_tensor(inputs, modes, rank, seed, noise=0.05):
+    X, _, _ = inputs.low_rank_tensor(modes, rank, seed=seed)
+    return np.abs(X) + noise * inputs.tensor(modes, seed + 1)
+
+
+def _check_nnls(gm, om, rep, ro, tol=1e-8, nonneg=True):
+    assert rep.nnls_status == 0 and ro.nnls_status == 0
+    for m in gm:
+        for f in m.factors:
+            assert (f >= 0.0).all() or not nonneg
+    _assert_models_match(gm, om, ro.X_norm ** 2, tol=tol)
+    for a, b in zip(gm, om):
+        for fa, fb in zip(a.factors, b.factors):
+            scale = max(np.abs(fb).max(), 1e-300)
+            assert np.abs(fa[fb == 0.0]).max(initial=0.0) <= 1e-9 * scale
+            assert np.abs(fb[fa == 0.0]).max(initial=0.0) <= 1e-9 * scale
+
+
+@pytest.mark.parametrize("modes,ranks,iters", [
+    ([30, 26, 22], [65], 6),
+    ([30, 26, 22], [70, 4, 129, 20], 5),            # two and three mask words next to one-word models
+    ([75, 12, 10], [66, 9], 6),                      # several row chunks per model
+    ([24, 20, 18], [256], 3),
+])
+def test_nnls_forced_iterations_vs_oracle(cc, oracle, inputs, modes, ranks, iters):
+    X = _nonneg_tensor(inputs, modes, 5, seed=17)
+    gm, om, rep, ro = _run_both(cc, oracle, inputs, modes, ranks, X, iters, update_method=1)
+    assert rep.iter == ro.iter == iters
+    _check_nnls(gm, om, rep, ro)
+    zeros = sum(int((f == 0.0).sum()) for m in gm for f in m.factors)
+    assert zeros > 50        # rank >> rank(X): most rows end with many constraints active
+
+
+def test_nnls_signed_tensor_queue_and_compress(cc, oracle, inputs):
+    """entries of both signs (warm start, both exchange loops, caught Cholesky failures) and a buffer smaller
+    than the queue: the extra mask words travel with their models' columns through eviction and compress."""
+    modes = [22, 19, 17]
+    ranks = [80, 5, 66, 12, 90, 3, 70]
+    X = inputs.tensor(modes, 5) - 0.1
+    gm, om, rep, ro = _run_both(cc, oracle, inputs, modes, ranks, X, 12, buffer=170, force_max_iter=0, tol=1e-4,
+                                update_method=1)
+    assert rep.iter == ro.iter
+    assert [m.iters for m in gm] == [m.iters for m in om]
+    _check_nnls(gm, om, rep, ro)
+
+
+def test_nnls_line_search_and_jackknife(cc, oracle, inputs):
+    """Ktensor::copy carries the active sets: the backup / revert moves every mask word of a model."""
+    modes, ranks = [20, 18, 16], [68, 4, 100]
+    X = _nonneg_tensor(inputs, modes, 5, seed=3, noise=0.3)
+    gm, om, rep, ro = _run_both(cc, oracle, inputs, modes, ranks, X, 9, line_search=1, line_search_interval=3,
+                                update_method=1)
+    assert (rep.ls_performed, rep.ls_failed) == (ro.ls_performed, ro.ls_failed)
+    assert rep.ls_performed > 0
+    _check_nnls(gm, om, rep, ro, nonneg=False)
+    jk = [(0, 2), (0, 11)]
+    gm, om, rep, ro = _run_both(cc, oracle, inputs, modes, [70, 6], X, 5, jk=jk, update_method=1)
+    _check_nnls(gm, om, rep, ro)
+    for (mode, fiber), m in zip(jk, gm):
+        assert not m.factors[mode][fiber, :].any()
+
+
+def test_rank_limit_fails_loudly(cc, inputs):
     modes = [30, 20, 10]
-    X = inputs.tensor(modes, 1)
-    for kw in (dict(update_method=1),):
-        e = cc.Engine(modes, 80)
-        e.set_tensor(X)
-        e.set_params(cc.default_params(max_iterations=3, force_max_iter=1, **kw))
-        (fs, lam), = inputs.model_factors(modes, [70], 1)
-        e.enqueue(cc.Model(fs, lam))
-        with pytest.raises(cc.CalsHipError) as ei:
-            e.run()
-        assert "rank > 64" in str(ei.value)
-        e.close()
     e = cc.Engine(modes, 300)
     (fs, lam), = inputs.model_factors(modes, [257], 1)
     with pytest.raises(cc.CalsHipError):
