@@ -24,7 +24,9 @@ def build(force=False, verbose=False):
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
     os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
     # objects built with other -D switches (CALS_DIAG, ring depths) must not survive into this build
-    variant = " ".join("%s=%s" % (k, os.environ[k]) for k in ("CALS_V3_RING", "CALS_DIAG", "CALS_TTM_RING")
+    # CALS_EXTRA_DEFS="-DNAME=1 ...": experiment switches (timing-only variants, see the kernels' #ifndef blocks)
+    variant = " ".join("%s=%s" % (k, os.environ[k])
+                       for k in ("CALS_V3_RING", "CALS_DIAG", "CALS_TTM_RING", "CALS_EXTRA_DEFS")
                        if os.environ.get(k)) or "production"
     stamp = os.path.join(HERE, "build", "variant.txt")
     if not os.path.exists(stamp) or open(stamp).read() != variant:
@@ -38,6 +40,7 @@ def build(force=False, verbose=False):
                 extra.append("-DCALS_DIAG=1")
             if os.environ.get("CALS_TTM_RING"):
                 extra.append("-DCALS_TTM_RING=%s" % os.environ["CALS_TTM_RING"])
+            extra += os.environ.get("CALS_EXTRA_DEFS", "").split()
             cmd = [hipcc] + FLAGS + extra + ["-x", "hip", "-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd))
