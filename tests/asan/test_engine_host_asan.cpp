@@ -57,11 +57,11 @@ static std::vector<HostModel> make_models(const std::vector<int64_t> &modes, con
 static void c_abi_life_cycles(int dtype) {
   const std::vector<int64_t> modes = {23, 17, 9};
   std::mt19937 gen(7 + dtype);
-  for (int round = 0; round < 6; round++) {
+  for (int round = 0; round < 7; round++) {  // 5, 6: ranks up to 150 (6: with the NNLS update and line search)
     std::vector<int> ranks;
     const int n_models = 20 + (int)(gen() % 60);
-    for (int k = 0; k < n_models; k++) ranks.push_back(1 + (int)(gen() % (round == 5 ? 150 : 12)));
-    const int64_t buffer = round == 5 ? 400 : 16 + (int64_t)(gen() % 40);
+    for (int k = 0; k < n_models; k++) ranks.push_back(1 + (int)(gen() % (round >= 5 ? 150 : 12)));
+    const int64_t buffer = round >= 5 ? 400 : 16 + (int64_t)(gen() % 40);
     auto models = make_models(modes, ranks, 100 + round);
     cals_hip_engine *e = nullptr;
     CHECK(cals_hip_create_ex(&e, 3, modes.data(), buffer, 0, dtype) == CALS_HIP_OK);
@@ -71,7 +71,7 @@ static void c_abi_life_cycles(int dtype) {
     cals_hip_default_params(&p);
     p.max_iterations = 25;
     p.line_search = (round % 2);
-    p.update_method = (round == 3) ? 1 : 0;
+    p.update_method = (round == 3 || round == 6) ? 1 : 0;
     p.always_evict_first = (round == 4);
     CHECK(cals_hip_set_params(e, &p) == CALS_HIP_OK);
     if (round == 2) CHECK(cals_hip_set_sweep_log(e, 1) == CALS_HIP_OK);
