@@ -174,6 +174,52 @@ def test_nnls_line_search_and_jackknife(cc, oracle, inputs):
         assert not m.factors[mode][fiber, :].any()
 
 
+def _random_cases(n, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n):
+        modes = [int(v) for v in rng.integers(12, 34, size=3)]
+        n_models = int(rng.integers(3, 9))
+        ranks = [int(rng.integers(65, 140)) if rng.integers(0, 2) else int(rng.integers(1, 40)) for _ in range(n_models)]
+        ranks[int(rng.integers(0, n_models))] = int(rng.integers(65, 140))
+        buffer = int(rng.integers(max(ranks), max(max(ranks) + 1, sum(ranks))))
+        out.append((modes, ranks, buffer, int(rng.integers(0, 2)), ["0", "A", "B", "M"][int(rng.integers(0, 4))],
+                    int(rng.integers(0, 1 << 30))))
+    return out
+
+
+_N_BIG = int(os.environ.get("CALS_SOAK_BIG", "10"))
+
+
+@pytest.mark.parametrize("modes,ranks,buffer,nnls,plan,seed", _random_cases(_N_BIG, 4242 + int(os.environ.get("CALS_SOAK_SEED", "0"))))
+def test_random_queue_life_cycle_with_big_ranks(cc, oracle, inputs, modes, ranks, buffer, nnls, plan, seed):
+    """random mixes of one-, two- and three-word models through a buffer smaller than the queue, both update
+    methods, every MTTKRP plan: same admission order, per-model sweep counts and fitted tensors as the oracle."""
+    from helpers import reconstruct
+    old = os.environ.get("CALS_HIP_TREE")
+    os.environ["CALS_HIP_TREE"] = plan
+    try:
+        X = inputs.low_rank_tensor(modes, 5, seed=seed % 1000)[0] + 0.05 * inputs.tensor(modes, seed % 977)
+        kw = dict(tol=1e-4, force_max_iter=0)
+        if nnls:
+            kw["update_method"] = 1
+            X = np.abs(X)
+        else:
+            kw.update(line_search=seed & 1, line_search_interval=3)
+        gm, om, rep, ro = _run_both(cc, oracle, inputs, modes, ranks, X, 12, buffer=buffer, **kw)
+        assert (rep.iter, rep.n_ktensors, rep.ktensor_comp_sum) == (ro.iter, ro.n_ktensors, ro.ktensor_comp_sum)
+        assert rep.nnls_status == 0 and ro.nnls_status == 0
+        for a, b in zip(gm, om):
+            assert a.iters == b.iters
+            d = np.linalg.norm(reconstruct(a.factors, a.lam, modes) - reconstruct(b.factors, b.lam, modes))
+            assert d <= 1e-8 * max(1.0, np.linalg.norm(X))
+    finally:
+        if old is None:
+            os.environ.pop("CALS_HIP_TREE", None)
+        else:
+            os.environ["CALS_HIP_TREE"] = old
+
+
 def test_rank_limit_fails_loudly(cc, inputs):
     modes = [30, 20, 10]
     e = cc.Engine(modes, 300)
