@@ -33,8 +33,13 @@ typedef double v4d __attribute__((ext_vector_type(4)));
     if (a.dbg_trace && a.mode == 0 && r == 20 && blockIdx.x < 24 && threadIdx.x == 0)         \
       a.dbg_trace[k] = __builtin_amdgcn_s_memtime();                                          \
   } while (0)
+#define UPD_STAMP_H(k)                                                                        \
+  do {                                                                                        \
+    if (a.dbg_trace && a.mode == 0 && threadIdx.x == 0) a.dbg_trace[k] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
 #else
 #define UPD_STAMP(k) do { } while (0)
+#define UPD_STAMP_H(k) do { } while (0)
 #endif
 
 __device__ __forceinline__ double wave_sum(double v) {
@@ -977,23 +982,60 @@ __device__ __attribute__((noinline)) void update_body_big(const UpdateArgs &a, i
   }
 }
 
+// One 16 x 16 tile (bi, bj) of P^T P over rows [row0, row1) as gramian_tile, with the operand loads of eight
+// k-steps issued before their MFMAs (the panel is in global memory here: one exposed round trip per eight
+// steps instead of one per step).  Trailing steps past row1 multiply zeros: same sums, same order.
+template <typename PTR>
+__device__ __forceinline__ v4d gramian_tile_b8(PTR panel, int row0, int row1, long long ld, int r, int lane,
+                                               int bi, int bj) {
+  const int krow = lane >> 4, lcol = lane & 15;
+  const bool ciok = (16 * bi + lcol) < r, cjok = (16 * bj + lcol) < r;
+  const long long offi = ld * (ciok ? 16 * bi + lcol : 0), offj = ld * (cjok ? 16 * bj + lcol : 0);
+  v4d acc = {0.0, 0.0, 0.0, 0.0};
+  for (int i0 = row0; i0 < row1; i0 += 32) {
+    double pi[8], pj[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = i0 + 4 * u + krow;
+      const int ic = i < row1 ? i : row0;
+      pi[u] = (double)panel[ic + offi];
+      pj[u] = (double)panel[ic + offj];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const bool rok = i0 + 4 * u + krow < row1;
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64((rok && ciok) ? pi[u] : 0.0, (rok && cjok) ? pj[u] : 0.0, acc, 0, 0, 0);
+    }
+  }
+  return acc;
+}
+
 // Ranks 65..CALS_GLD: no register file or LDS holds an r x r matrix or a factor row of this size, so H / L
-// live in a global scratch block per workgroup (a.hscratch, L2 resident) and every row is solved IN PLACE
-// in the factor panel (column accesses are coalesced over the rows a wavefront holds; L entries are
-// broadcast loads).  Same operations as update_body_big -- unblocked Cholesky in dpotf2's order, dtrsm
-// Right/Lower/Trans then Right/Lower/NoTrans row by row, |L^-1 g_i|^2 for the error term -- with the whole
-// workgroup on the factorisation (lane = row no longer fits one wave).  Built to be right, not fast: the
-// reference's typical ranks are <= 20 and everything up to 64 runs the bodies above.  After the NNLS update
-// (a.rowdot, nnls_huge_kernel) the panel already holds the solution and only the tail runs.
+// live in a global scratch block per workgroup (a.hscratch, L2 resident) and the rows are solved through the
+// factor panel itself, one row per thread, SIXTEEN COLUMNS AT A TIME in registers:
+//   * dpotf2 on the whole workgroup (thread = row; column j needs sum_{k<j} L[i][k] L[j][k]: own row
+//     coalesced over the threads, row j broadcast); every L[i][j] is also written TRANSPOSED into the upper
+//     triangle of the block, so that both substitutions below read 16 consecutive doubles per step; the
+//     loads of eight k go out before their FMAs (an exposed L2 round trip per FMA was 85 % of this body);
+//   * B := B inv(L^T), left-looking per 16-column block: x_b -= L[b, k] x_k over all earlier columns k in
+//     ascending order, then the 16 x 16 triangle -- the operations and their order are dtrsm's
+//     Right/Lower/Trans; B := B inv(L) block by block from the right, later columns first, then the triangle
+//     (the sums of a column run over the same terms as dtrsm's in a different order: rounding only);
+//   * H is padded with the identity up to a multiple of 16 columns, so no step carries a `c < r` guard.
+// Same tail as the other bodies (statistics, scaling, Gramian on the matrix cores, error).  After the NNLS
+// update (a.rowdot, nnls_huge_kernel) the panel already holds the solution and only the tail runs.
 template <typename T>
 __device__ __attribute__((noinline)) void update_body_huge(const UpdateArgs &a, int slot, int r,
                                                            UpdShared &sh) {
   constexpr int LD = CALS_GLD;
+  constexpr int XB = 16;
+  typedef double v2d __attribute__((ext_vector_type(2)));
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int col = a.mt.col[slot];
   const long long iters = a.mt.iters[slot];
   const int jkf = (a.mt.jk_mode[slot] == a.mode) ? a.mt.jk_fiber[slot] : -1;
   const int I = a.I;
+  const int rp = (r + XB - 1) / XB * XB;
   double *gpb = reinterpret_cast<double *>(upd_dyn);         // [UPD_WAVES][256] partial Gramian tiles
   __shared__ double s_piv;
   __shared__ int s_info, s_block;
@@ -1001,33 +1043,46 @@ __device__ __attribute__((noinline)) void update_body_huge(const UpdateArgs &a, 
   // in flight and zeroes the counter before the launch)
   const double *rowdot = a.rowdot ? a.rowdot + (long long)I * blockIdx.x : nullptr;
   const bool solved = rowdot != nullptr;
+  UPD_STAMP_H(0);
   if (tid == 0) s_block = solved ? 0 : atomicAdd(a.hcounter, 1);
   __syncthreads();
-  double *H = a.hscratch + (long long)s_block * LD * LD;  // r x r, ld LD
+  double *__restrict__ H = a.hscratch + (long long)s_block * LD * LD;  // rp x rp, ld LD
 
-  for (int e = tid; e < (solved ? 0 : r * r); e += UPD_THREADS) {
-    const int i = e % r, j = e / r;
-    double h = 1.0;
-    for (int m = 0; m < a.n_modes; ++m)
-      if (m != a.mode) h *= a.gram[m][i + CALS_GLD * (long long)(col + j)];
+  for (int e = tid; e < (solved ? 0 : rp * rp); e += UPD_THREADS) {
+    const int i = e % rp, j = e / rp;
+    double h = (i == j) ? 1.0 : 0.0;  // identity padding: L comes out as diag(L_r, I)
+    if (i < r && j < r) {
+      h = 1.0;
+      for (int m = 0; m < a.n_modes; ++m)
+        if (m != a.mode) h *= a.gram[m][i + CALS_GLD * (long long)(col + j)];
+    }
     H[i + LD * j] = h;
   }
   if (tid == 0) s_info = 0;
   __threadfence_block();
   __syncthreads();
+  UPD_STAMP_H(1);
   // dpotf2, column j: s_i = H[i][j] - sum_{k<j} L[i][k] L[j][k] for the rows i >= j, one row per thread
   for (int j = 0; j < (solved ? 0 : r); ++j) {
-    double sv[(CALS_GLD + UPD_THREADS - 1) / UPD_THREADS];
+    const int i = j + tid;
+    double s_ = 0.0;
+    if (i < r) {
+      s_ = H[i + LD * j];
+      const double *own = H + i;                 // L[i][k] at own[LD * k]
+      const double *piv = H + (long long)LD * j; // L[j][k] at piv[k] (the transposed copy)
+      int k = 0;
+      for (; k + 16 <= j; k += 16) {
+        double lo[16];
+        v2d pv[8];
 #pragma unroll
-    for (int q = 0; q < (CALS_GLD + UPD_THREADS - 1) / UPD_THREADS; ++q) {
-      const int i = j + tid + q * UPD_THREADS;
-      sv[q] = 0.0;
-      if (i < r) {
-        double s_ = H[i + LD * j];
-        for (int k = 0; k < j; ++k) s_ -= H[i + LD * k] * H[j + LD * k];
-        sv[q] = s_;
-        if (i == j) s_piv = s_;
+        for (int u = 0; u < 16; ++u) lo[u] = own[(long long)LD * (k + u)];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) pv[u] = *reinterpret_cast<const v2d *>(piv + k + 2 * u);
+#pragma unroll
+        for (int u = 0; u < 16; ++u) s_ -= lo[u] * pv[u >> 1][u & 1];
       }
+      for (; k < j; ++k) s_ -= own[(long long)LD * k] * piv[k];
+      if (i == j) s_piv = s_;
     }
     __syncthreads();
     const double ajj = s_piv;
@@ -1039,24 +1094,24 @@ __device__ __attribute__((noinline)) void update_body_huge(const UpdateArgs &a, 
       break;
     }
     const double ljj = sqrt(ajj);
-#pragma unroll
-    for (int q = 0; q < (CALS_GLD + UPD_THREADS - 1) / UPD_THREADS; ++q) {
-      const int i = j + tid + q * UPD_THREADS;
-      if (i == j)
-        H[j + LD * j] = ljj;
-      else if (i < r)
-        H[i + LD * j] = sv[q] / ljj;
+    if (i == j) {
+      H[j + LD * j] = ljj;
+    } else if (i < r) {
+      const double lij = s_ / ljj;
+      H[i + LD * j] = lij;
+      H[j + (long long)LD * i] = lij;
     }
     __threadfence_block();
     __syncthreads();
   }
   __syncthreads();
   if (!solved)
-    for (int k = tid; k < r; k += UPD_THREADS) sh.dinv[k] = 1.0 / H[k + LD * k];
+    for (int k = tid; k < rp; k += UPD_THREADS) sh.dinv[k] = 1.0 / H[k + LD * k];
   if (tid == 0) a.mt.potrf_info[slot] = s_info;
   __threadfence_block();
   __syncthreads();
   const double *dinv = sh.dinv;
+  UPD_STAMP_H(2);
 
   T *fac = static_cast<T *>(a.factor) + (long long)I * col;
   const bool first = (iters == 1);
@@ -1070,32 +1125,99 @@ __device__ __attribute__((noinline)) void update_body_huge(const UpdateArgs &a, 
         for (int c = 0; c < r; ++c) x[(long long)I * c] = (T)((double)x[(long long)I * c] * 0.0);
       continue;
     }
-    // B := B * inv(L^T): forward substitution along the row
-    for (int k = 0; k < r; ++k) {
-      const double xk = dinv[k] * (double)x[(long long)I * k];
-      x[(long long)I * k] = (T)xk;
-      for (int j = k + 1; j < r; ++j)
-        x[(long long)I * j] = (T)((double)x[(long long)I * j] - H[j + LD * k] * xk);
-    }
-    if (i != jkf)
-      for (int c = 0; c < r; ++c) {
-        const double v = (double)x[(long long)I * c];
-        t3 += v * v;
+    // B := B * inv(L^T)
+    for (int kb = 0; kb < rp; kb += XB) {
+      double xb[XB];
+#pragma unroll
+      for (int c = 0; c < XB; ++c) xb[c] = (kb + c < r) ? (double)x[(long long)I * (kb + c)] : 0.0;
+      for (int k = 0; k < kb; k += 4) {  // kb is a multiple of 16: whole batches; four columns' loads in flight
+        double xk[4];
+        v2d h[4][XB / 2];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          xk[u] = (double)x[(long long)I * (k + u)];
+          const v2d *hp = reinterpret_cast<const v2d *>(H + kb + (long long)LD * (k + u));  // L[kb + c][k + u]
+#pragma unroll
+          for (int c = 0; c < XB / 2; ++c) h[u][c] = hp[c];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+          for (int c = 0; c < XB; c += 2) {
+            xb[c] -= h[u][c >> 1][0] * xk[u];
+            xb[c + 1] -= h[u][c >> 1][1] * xk[u];
+          }
+        }
       }
-    // B := B * inv(L): backward substitution
-    for (int j = r - 1; j >= 0; --j) {
-      double s_ = (double)x[(long long)I * j];
-      for (int k = j + 1; k < r; ++k) s_ -= H[k + LD * j] * (double)x[(long long)I * k];
-      x[(long long)I * j] = (T)(dinv[j] * s_);
+#pragma unroll
+      for (int k = 0; k < XB; ++k) {
+        const double xk = dinv[kb + k] * xb[k];
+        xb[k] = xk;
+        const v2d *hp = reinterpret_cast<const v2d *>(H + kb + (long long)LD * (kb + k));  // L[kb + c][kb + k]
+#pragma unroll
+        for (int c = (k + 1) & ~1; c < XB; c += 2) {
+          const v2d h = hp[c >> 1];
+          if (c > k) xb[c] -= h[0] * xk;
+          xb[c + 1] -= h[1] * xk;
+        }
+      }
+      if (i != jkf) {
+#pragma unroll
+        for (int c = 0; c < XB; ++c) t3 += xb[c] * xb[c];  // padding columns hold exact zeros
+      }
+#pragma unroll
+      for (int c = 0; c < XB; ++c)
+        if (kb + c < r) x[(long long)I * (kb + c)] = (T)xb[c];
     }
-    if (i == jkf)
-      for (int c = 0; c < r; ++c) x[(long long)I * c] = (T)((double)x[(long long)I * c] * 0.0);
+    // B := B * inv(L)
+    for (int jb = rp - XB; jb >= 0; jb -= XB) {
+      double xb[XB];
+#pragma unroll
+      for (int c = 0; c < XB; ++c) xb[c] = (jb + c < r) ? (double)x[(long long)I * (jb + c)] : 0.0;
+      // columns jb + 16 .. rp - 1 in batches of four (the padding columns hold x = 0 and L = identity rows:
+      // they are skipped by reading x as 0 there)
+      for (int k = jb + XB; k < rp; k += 4) {
+        double xk[4];
+        v2d h[4][XB / 2];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          xk[u] = (k + u < r) ? (double)x[(long long)I * (k + u)] : 0.0;
+          const v2d *hp = reinterpret_cast<const v2d *>(H + jb + (long long)LD * (k + u));  // L[k + u][jb + c], transposed copy
+#pragma unroll
+          for (int c = 0; c < XB / 2; ++c) h[u][c] = hp[c];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+          for (int c = 0; c < XB; c += 2) {
+            xb[c] -= h[u][c >> 1][0] * xk[u];
+            xb[c + 1] -= h[u][c >> 1][1] * xk[u];
+          }
+        }
+      }
+#pragma unroll
+      for (int j = XB - 1; j >= 0; --j) {
+        double s_ = xb[j];
+        const v2d *hp = reinterpret_cast<const v2d *>(H + jb + (long long)LD * (jb + j));  // L[jb + k][jb + j]
+#pragma unroll
+        for (int k = (j + 1) & ~1; k < XB; k += 2) {
+          const v2d h = hp[k >> 1];
+          if (k > j) s_ -= h[0] * xb[k];
+          s_ -= h[1] * xb[k + 1];
+        }
+        xb[j] = dinv[jb + j] * s_;
+      }
+#pragma unroll
+      for (int c = 0; c < XB; ++c)
+        if (jb + c < r) x[(long long)I * (jb + c)] = (T)((i == jkf) ? xb[c] * 0.0 : xb[c]);
+    }
   }
   t3 = wave_sum(t3);
   if (lane == 0) sh.redt[wave] = t3;
   __threadfence_block();
   __syncthreads();
   t3 = sh.redt[0] + sh.redt[1] + sh.redt[2] + sh.redt[3];
+  UPD_STAMP_H(3);
 
   for (int c = wave; c < r; c += UPD_WAVES) {  // column scales (Ktensor::normalize(mode, iteration))
     const T *cp = fac + (long long)I * c;
@@ -1137,6 +1259,7 @@ __device__ __attribute__((noinline)) void update_body_huge(const UpdateArgs &a, 
     }
   }
   __syncthreads();
+  UPD_STAMP_H(4);
   const double *lams = sh.lams;
   for (int c = 0; c < r; ++c) {
     const double lam = lams[c];
@@ -1147,6 +1270,7 @@ __device__ __attribute__((noinline)) void update_body_huge(const UpdateArgs &a, 
   __threadfence_block();
   __syncthreads();
 
+  UPD_STAMP_H(5);
   {  // update_gramian, one 16 x 16 tile pair at a time, rows split over the waves
     double *g = a.gram[a.mode] + CALS_GLD * (long long)col;
     const int nt = (r + 15) >> 4;
@@ -1155,7 +1279,7 @@ __device__ __attribute__((noinline)) void update_body_huge(const UpdateArgs &a, 
     const int krow = lane >> 4, lcol = lane & 15;
     for (int bi = 0; bi < nt; ++bi)
       for (int bj = bi; bj < nt; ++bj) {
-        const v4d t = gramian_tile((const T *)fac, row0, row1, (long long)I, r, lane, bi, bj);
+        const v4d t = gramian_tile_b8((const T *)fac, row0, row1, (long long)I, r, lane, bi, bj);
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) gpb[wave * 256 + lane * 4 + reg] = t[reg];
         __syncthreads();
@@ -1175,6 +1299,7 @@ __device__ __attribute__((noinline)) void update_body_huge(const UpdateArgs &a, 
       }
   }
 
+  UPD_STAMP_H(6);
   if (a.is_last) {
     __threadfence_block();
     __syncthreads();

@@ -348,6 +348,7 @@ __global__ void __launch_bounds__(256) nnls_kernel(const NnlsArgs a) {
 namespace {
 
 typedef unsigned long long u64;
+typedef double v2d_t __attribute__((ext_vector_type(2)));
 
 struct HugeWave {
   double *Lt;  // global: L[p][k] at Lt[k * CALS_GLD + p]
@@ -394,7 +395,15 @@ __device__ bool solve_passive_huge(const double *Hs, int r, HugeWave &ws, const 
 #pragma unroll
   for (int q = 0; q < NNLS_HQ; ++q) same = same && (pas[q] == ws.cached[q]);
   if (same) {
-    for (int j = 0; j < np; ++j) {  // L z = b with the cached factor, same operation order
+    // L z = b with the cached factor, same operation order; column j + 1 of the factor is fetched while
+    // column j is applied (a step then costs two LDS round trips, not an L2 one)
+    double lc[NNLS_HQ], ln[NNLS_HQ];
+#pragma unroll
+    for (int q = 0; q < NNLS_HQ; ++q) lc[q] = (q < nq) ? ws.Lt[lane + 64 * q] : 0.0;
+    for (int j = 0; j < np; ++j) {
+      const int jn = (j + 1 < np) ? j + 1 : j;
+#pragma unroll
+      for (int q = 0; q < NNLS_HQ; ++q) ln[q] = (q < nq) ? ws.Lt[(size_t)jn * LD + lane + 64 * q] : 0.0;
       const double zj = ws.cv[j] / ws.dgs[j];
       WAVE_SYNC();
 #pragma unroll
@@ -404,10 +413,12 @@ __device__ bool solve_passive_huge(const double *Hs, int r, HugeWave &ws, const 
           if (p == j)
             ws.cv[p] = zj;
           else if (p < np && p > j)
-            ws.cv[p] -= ws.Lt[(size_t)j * LD + p] * zj;
+            ws.cv[p] -= lc[q] * zj;
         }
       }
       WAVE_SYNC();
+#pragma unroll
+      for (int q = 0; q < NNLS_HQ; ++q) lc[q] = ln[q];
     }
   } else {
     ws.has_cache = false;
@@ -420,10 +431,33 @@ __device__ bool solve_passive_huge(const double *Hs, int r, HugeWave &ws, const 
         const int p = lane + 64 * q;
         sv[q] = (q < nq && p < np && p > j) ? Hs[ws.idx[p] + (size_t)r * ij] : 0.0;
       }
-      const double *Ltj = ws.Lt + j, *Ltp = ws.Lt + lane;
-#pragma unroll 2
-      for (int k = 0; k < j; ++k) {  // the subtractions stay in k order; rows outside (j, np) compute unused values
-        const double ljk = Ltj[(size_t)k * LD];
+      // the subtractions stay in k order; rows outside (j, np) compute unused values.  Row j of the factor
+      // comes from the row-contiguous copy (16-byte broadcast loads); the loads of eight k go out before
+      // their FMAs: one exposed L2 round trip per eight columns instead of one per column.
+      const double *Lrj = ws.Lr + (size_t)j * LD, *Ltp = ws.Lt + lane;
+      int k = 0;
+      for (; k + 8 <= j; k += 8) {
+        v2d_t pv[4];
+        double lp[NNLS_HQ][8];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) pv[u] = *reinterpret_cast<const v2d_t *>(Lrj + k + 2 * u);
+#pragma unroll
+        for (int q = 0; q < NNLS_HQ; ++q)
+          if (q < nq) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) lp[q][u] = Ltp[(size_t)(k + u) * LD + 64 * q];
+          }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const double ljk = pv[u >> 1][u & 1];
+          ajj -= ljk * ljk;
+#pragma unroll
+          for (int q = 0; q < NNLS_HQ; ++q)
+            if (q < nq) sv[q] -= lp[q][u] * ljk;
+        }
+      }
+      for (; k < j; ++k) {
+        const double ljk = Lrj[k];
         ajj -= ljk * ljk;
 #pragma unroll
         for (int q = 0; q < NNLS_HQ; ++q)
@@ -456,20 +490,30 @@ __device__ bool solve_passive_huge(const double *Hs, int r, HugeWave &ws, const 
     for (int q = 0; q < NNLS_HQ; ++q) ws.cached[q] = pas[q];
     ws.has_cache = true;
   }
-  for (int j = np - 1; j >= 0; --j) {  // L^T x = z
-    const double xj = ws.cv[j] / ws.dgs[j];
-    WAVE_SYNC();
+  {  // L^T x = z, row j - 1 of the factor fetched while row j is applied
+    double lc[NNLS_HQ], ln[NNLS_HQ];
 #pragma unroll
-    for (int q = 0; q < NNLS_HQ; ++q) {
-      const int p = lane + 64 * q;
-      if (q < nq) {
-        if (p == j)
-          ws.cv[p] = xj;
-        else if (p < j)
-          ws.cv[p] -= ws.Lr[(size_t)j * LD + p] * xj;
+    for (int q = 0; q < NNLS_HQ; ++q) lc[q] = (q < nq) ? ws.Lr[(size_t)(np - 1) * LD + lane + 64 * q] : 0.0;
+    for (int j = np - 1; j >= 0; --j) {
+      const int jn = j > 0 ? j - 1 : 0;
+#pragma unroll
+      for (int q = 0; q < NNLS_HQ; ++q) ln[q] = (q < nq) ? ws.Lr[(size_t)jn * LD + lane + 64 * q] : 0.0;
+      const double xj = ws.cv[j] / ws.dgs[j];
+      WAVE_SYNC();
+#pragma unroll
+      for (int q = 0; q < NNLS_HQ; ++q) {
+        const int p = lane + 64 * q;
+        if (q < nq) {
+          if (p == j)
+            ws.cv[p] = xj;
+          else if (p < j)
+            ws.cv[p] -= lc[q] * xj;
+        }
       }
+      WAVE_SYNC();
+#pragma unroll
+      for (int q = 0; q < NNLS_HQ; ++q) lc[q] = ln[q];
     }
-    WAVE_SYNC();
   }
 #pragma unroll
   for (int q = 0; q < NNLS_HQ; ++q) {
@@ -497,6 +541,7 @@ __device__ __forceinline__ void multipliers_huge(const double *Hs, int r, HugeWa
     acc[q] = 0.0;
     row[q] = (lane + 64 * q < r) ? lane + 64 * q : 0;
   }
+#pragma unroll 4
   for (int j = 0; j < r; ++j) {
     const double dj = ws.dv[j];
 #pragma unroll
