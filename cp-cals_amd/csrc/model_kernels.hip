@@ -768,218 +768,10 @@ __device__ __attribute__((noinline)) void update_body_lds(const UpdateArgs &a, i
   }
 }
 
-// Ranks 33..64: the same update with H (64 x 64) in dynamic LDS and the factor panel going through
-// HBM between the phases (a thread still keeps its row in registers for the two solves).  The
-// error term sum_c A_unnorm[i,c] G[i,c] is accumulated as |L^-1 g_i|^2 (algebraically the same;
-// G is not kept next to the 64-entry row).  Slower than the bodies above by design: it only has to
-// be right.
-template <typename T>
-__device__ __attribute__((noinline)) void update_body_big(const UpdateArgs &a, int slot, int r,
-                                                          UpdShared &sh) {
-  constexpr int RM = CALS_RMAX;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int col = a.mt.col[slot];
-  const long long iters = a.mt.iters[slot];
-  const int jkf = (a.mt.jk_mode[slot] == a.mode) ? a.mt.jk_fiber[slot] : -1;
-  const int I = a.I;
-  double *Hb = reinterpret_cast<double *>(upd_dyn);  // RM x RM
-  double *gpb = Hb + RM * RM;                        // [UPD_WAVES][256] partial Gramian tiles
-
-  for (int e = tid; e < r * r; e += UPD_THREADS) {
-    const int i = e % r, j = e / r;
-    double h = 1.0;
-    for (int m = 0; m < a.n_modes; ++m)
-      if (m != a.mode) h *= a.gram[m][i + CALS_GLD * (long long)(col + j)];
-    Hb[i + RM * j] = h;
-  }
-  __syncthreads();
-  // NNLS update: the panel already holds the constrained solution (nnls_kernel.hip)
-  const double *rowdot = a.rowdot ? a.rowdot + (long long)a.I * blockIdx.x : nullptr;
-  const bool solved = rowdot != nullptr;
-  if (wave == 0 && !solved) {  // dpotf2 order, lane = row (r <= 64 = one wave)
-    int info = 0;
-    for (int j = 0; j < r; ++j) {
-      const bool below = lane > j && lane < r;
-      const int lrow = below ? lane : j;
-      double ajj = Hb[j + RM * j];
-      double sv = below ? Hb[lane + RM * j] : 0.0;
-      for (int k = 0; k < j; ++k) {
-        const double ljk = Hb[j + RM * k];
-        ajj -= ljk * ljk;
-        sv -= Hb[lrow + RM * k] * ljk;
-      }
-      if (!(ajj > 0.0)) {
-        if (lane == 0) Hb[j + RM * j] = ajj;
-        info = j + 1;
-        break;
-      }
-      ajj = sqrt(ajj);
-      if (lane == j)
-        Hb[j + RM * j] = ajj;
-      else if (below)
-        Hb[lane + RM * j] = sv / ajj;
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    }
-    if (lane < r) sh.dinv[lane] = 1.0 / Hb[lane + RM * lane];
-    if (lane == 0) a.mt.potrf_info[slot] = info;
-  }
-  __syncthreads();
-  const double *dinv = sh.dinv;
-
-  T *fac = static_cast<T *>(a.factor) + (long long)I * col;
-  const bool first = (iters == 1);
-  double t3 = 0.0;
-  for (int i = tid; i < I; i += UPD_THREADS) {
-    double x[RM];
-    asm volatile("" ::: "memory");
-#pragma unroll
-    for (int c = 0; c < RM; ++c) x[c] = (c < r) ? (double)fac[i + (long long)I * c] : 0.0;
-    if (!solved) {
-#pragma unroll
-      for (int k = 0; k < RM; ++k) {
-        if (k < r) {
-          x[k] = dinv[k] * x[k];
-#pragma unroll
-          for (int j = k + 1; j < RM; ++j)
-            if (j < r) x[j] -= Hb[j + RM * k] * x[k];
-        }
-      }
-      if (i != jkf) {  // a jackknife model's zeroed fiber (below) has no share in term3
-#pragma unroll
-        for (int c = 0; c < RM; ++c)
-          if (c < r) t3 += x[c] * x[c];
-      }
-#pragma unroll
-      for (int j = RM - 1; j >= 0; --j) {
-        if (j < r) {
-#pragma unroll
-          for (int k = j + 1; k < RM; ++k)
-            if (k < r) x[j] -= Hb[k + RM * j] * x[k];
-          x[j] = dinv[j] * x[j];
-        }
-      }
-    } else if (i != jkf) {
-      t3 += rowdot[i];
-    }
-    if (i == jkf) {
-      // the reference zeroes the row after the solve (ktensor.h:316-325)
-#pragma unroll
-      for (int c = 0; c < RM; ++c) x[c] *= 0.0;
-    }
-#pragma unroll
-    for (int c = 0; c < RM; ++c)
-      if (c < r) fac[i + (long long)I * c] = (T)x[c];
-  }
-  t3 = wave_sum(t3);
-  if (lane == 0) sh.redt[wave] = t3;
-  __threadfence_block();
-  __syncthreads();
-  t3 = sh.redt[0] + sh.redt[1] + sh.redt[2] + sh.redt[3];
-
-  for (int c = wave; c < r; c += UPD_WAVES) {  // column scales (Ktensor::normalize(mode, iteration))
-    const T *cp = fac + (long long)I * c;
-    double lam;
-    if (first) {
-      double ss = 0.0;
-      for (int i = lane; i < I; i += 64) {
-        const double x = (double)cp[i];
-        ss += x * x;
-      }
-      lam = sqrt(wave_sum(ss));
-    } else {
-      double m = -1.0, v = 0.0;
-      int ix = 0x7fffffff;
-      for (int i = lane; i < I; i += 64) {
-        const double x = (double)cp[i];
-        const double ax = fabs(x);
-        if (ax > m) {
-          m = ax;
-          v = x;
-          ix = i;
-        }
-      }
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) {
-        const double m2 = __shfl_xor(m, off);
-        const double v2 = __shfl_xor(v, off);
-        const int i2 = __shfl_xor(ix, off);
-        const bool take = (m2 > m) || (m2 == m && i2 < ix);
-        m = take ? m2 : m;
-        v = take ? v2 : v;
-        ix = take ? i2 : ix;
-      }
-      lam = v;
-    }
-    if (lane == 0) {
-      sh.lams[c] = lam;
-      a.lambda[col + c] = lam;
-    }
-  }
-  __syncthreads();
-  const double *lams = sh.lams;
-  for (int c = 0; c < r; ++c) {
-    const double lam = lams[c];
-    if (lam != 0.0)
-      for (int i = tid; i < I; i += UPD_THREADS)
-        fac[i + (long long)I * c] = (T)((1.0 / lam) * (double)fac[i + (long long)I * c]);
-  }
-  __threadfence_block();
-  __syncthreads();
-
-  {  // update_gramian, one 16 x 16 tile pair at a time, rows split over the waves
-    double *g = a.gram[a.mode] + CALS_GLD * (long long)col;
-    const int nt = (r + 15) >> 4;
-    const int chunk = ((I + UPD_WAVES - 1) / UPD_WAVES + 3) / 4 * 4;
-    const int row0 = wave * chunk, row1 = min(I, row0 + chunk);
-    const int krow = lane >> 4, lcol = lane & 15;
-    for (int bi = 0; bi < nt; ++bi)
-      for (int bj = bi; bj < nt; ++bj) {
-        const v4d t = gramian_tile((const T *)fac, row0, row1, (long long)I, r, lane, bi, bj);
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) gpb[wave * 256 + lane * 4 + reg] = t[reg];
-        __syncthreads();
-        if (wave == 0) {
-#pragma unroll
-          for (int reg = 0; reg < 4; ++reg) {
-            const int e = lane * 4 + reg;
-            const double v = ((gpb[e] + gpb[256 + e]) + gpb[512 + e]) + gpb[768 + e];
-            const int row = 16 * bi + krow + 4 * reg, cc = 16 * bj + lcol;
-            if (row < r && cc < r) {
-              g[row + CALS_GLD * cc] = v;
-              g[cc + CALS_GLD * row] = v;
-            }
-          }
-        }
-        __syncthreads();
-      }
-  }
-
-  if (a.is_last) {
-    __threadfence_block();
-    __syncthreads();
-    double t2 = 0.0;
-    for (int e = tid; e < r * r; e += UPD_THREADS) {
-      const int i = e % r, j = e / r;
-      double h = 1.0;
-      for (int m = 0; m < a.n_modes; ++m) h *= a.gram[m][i + CALS_GLD * (long long)(col + j)];
-      t2 += lams[i] * lams[j] * h;
-    }
-    t2 = wave_sum(t2);
-    __syncthreads();
-    if (lane == 0) sh.redt[wave] = t2;
-    __syncthreads();
-    if (tid == 0) {
-      t2 = sh.redt[0] + sh.redt[1] + sh.redt[2] + sh.redt[3];
-      const int jm = a.mt.jk_mode[slot];
-      const double xn = (jm >= 0) ? a.jk_norms[a.mt.jk_fiber[slot]] : a.X_norm;
-      const double e2 = fmax(xn * xn + t2 - 2.0 * t3, 0.0);
-      const double err = sqrt(e2);
-      a.mt.err[slot] = err;
-      const double of = a.mt.fit[slot];
-      a.mt.old_fit[slot] = of;
-      a.mt.fit[slot] = 1.0 - fabs(err) / a.X_norm;
-    }
-  }
+__device__ __forceinline__ double lane_bcast(double v, int l) {  // l wave-uniform
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+  return __hiloint2double(hi, lo);
 }
 
 // One 16 x 16 tile (bi, bj) of P^T P over rows [row0, row1) as gramian_tile, with the operand loads of eight
@@ -1024,10 +816,15 @@ __device__ __forceinline__ v4d gramian_tile_b8(PTR panel, int row0, int row1, lo
 //   * H is padded with the identity up to a multiple of 16 columns, so no step carries a `c < r` guard.
 // Same tail as the other bodies (statistics, scaling, Gramian on the matrix cores, error).  After the NNLS
 // update (a.rowdot, nnls_huge_kernel) the panel already holds the solution and only the tail runs.
-template <typename T>
+// HLDS (ranks 33..64): the same code with the H / L block in dynamic LDS (ld 66: the transposed-copy stores of a
+// wave then spread over 16 banks instead of one) -- the Cholesky panels run on one wave, the substitutions read L
+// with ds_read_b128.  (Round 1's body for these ranks unrolled a 64 x 64 guarded substitution per row: 4096 LDS
+// reads and exec-mask guards per thread, 0.7 ms per launch at rank 64 -- slower than this code through L2.)
+#define UPD_HLDS_LD 66
+template <typename T, bool HLDS>
 __device__ __attribute__((noinline)) void update_body_huge(const UpdateArgs &a, int slot, int r,
                                                            UpdShared &sh) {
-  constexpr int LD = CALS_GLD;
+  constexpr int LD = HLDS ? UPD_HLDS_LD : CALS_GLD;
   constexpr int XB = 16;
   typedef double v2d __attribute__((ext_vector_type(2)));
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1036,17 +833,24 @@ __device__ __attribute__((noinline)) void update_body_huge(const UpdateArgs &a, 
   const int jkf = (a.mt.jk_mode[slot] == a.mode) ? a.mt.jk_fiber[slot] : -1;
   const int I = a.I;
   const int rp = (r + XB - 1) / XB * XB;
-  double *gpb = reinterpret_cast<double *>(upd_dyn);         // [UPD_WAVES][256] partial Gramian tiles
+  // [UPD_WAVES][256] partial Gramian tiles
+  double *gpb = reinterpret_cast<double *>(upd_dyn) + (HLDS ? UPD_HLDS_LD * CALS_RMAX : 0);
   __shared__ double s_piv;
-  __shared__ int s_info, s_block;
+  // the diagonal block of a Cholesky panel: in the Gramian-partials area of UpdShared, idle at that point
+  double (*s_dblk)[XB + 1] = reinterpret_cast<double (*)[XB + 1]>(&sh.gp[0][0][0]);
+  __shared__ int s_info, s_block, s_fail;
   // scratch blocks are handed out in arrival order (the engine sizes the pool by the number of such models
   // in flight and zeroes the counter before the launch)
   const double *rowdot = a.rowdot ? a.rowdot + (long long)I * blockIdx.x : nullptr;
   const bool solved = rowdot != nullptr;
   UPD_STAMP_H(0);
-  if (tid == 0) s_block = solved ? 0 : atomicAdd(a.hcounter, 1);
+  if (tid == 0) s_block = (solved || HLDS) ? 0 : atomicAdd(a.hcounter, 1);
   __syncthreads();
-  double *__restrict__ H = a.hscratch + (long long)s_block * LD * LD;  // rp x rp, ld LD
+  double *__restrict__ H;  // rp x rp, ld LD
+  if constexpr (HLDS)
+    H = reinterpret_cast<double *>(upd_dyn);
+  else
+    H = a.hscratch + (long long)s_block * LD * LD;
 
   for (int e = tid; e < (solved ? 0 : rp * rp); e += UPD_THREADS) {
     const int i = e % rp, j = e / rp;
@@ -1062,44 +866,116 @@ __device__ __attribute__((noinline)) void update_body_huge(const UpdateArgs &a, 
   __threadfence_block();
   __syncthreads();
   UPD_STAMP_H(1);
-  // dpotf2, column j: s_i = H[i][j] - sum_{k<j} L[i][k] L[j][k] for the rows i >= j, one row per thread
-  for (int j = 0; j < (solved ? 0 : r); ++j) {
-    const int i = j + tid;
-    double s_ = 0.0;
-    if (i < r) {
-      s_ = H[i + LD * j];
-      const double *own = H + i;                 // L[i][k] at own[LD * k]
-      const double *piv = H + (long long)LD * j; // L[j][k] at piv[k] (the transposed copy)
-      int k = 0;
-      for (; k + 16 <= j; k += 16) {
-        double lo[16];
-        v2d pv[8];
+  // dpotf2 in panels of 16 columns, thread = row (rp <= 256 rows, the padding rows are identity rows):
+  //   S[i][c] = H[i][jb + c] - sum_{k < jb} L[i][k] L[jb + c][k]   in registers, four k in flight;
+  //   the 16 x 16 diagonal block goes to LDS, where wave 0 factors it column by column (right-looking inside
+  //   the block); every row below it then applies the block's columns to its own 16 values.
+  // Every entry sees the subtractions of dpotf2 in dpotf2's order (k ascending), so the factor is the unblocked
+  // one bit for bit; a non-positive pivot stops at its column with the earlier columns final and the rest of H
+  // untouched, exactly the state the column-by-column form leaves (update.cpp:183-185 only logs info).
+  for (int jb = 0; jb < (solved ? 0 : rp); jb += XB) {
+    const int i = tid;
+    const bool act = i >= jb && i < rp;
+    double sacc[XB];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) lo[u] = own[(long long)LD * (k + u)];
+    for (int c = 0; c < XB; ++c) sacc[c] = 0.0;
+    if (act) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) pv[u] = *reinterpret_cast<const v2d *>(piv + k + 2 * u);
+      for (int c = 0; c < XB; ++c) sacc[c] = H[i + (long long)LD * (jb + c)];
+      for (int k = 0; k < jb; k += 4) {
+        double own[4];
+        v2d pan[4][XB / 2];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) s_ -= lo[u] * pv[u >> 1][u & 1];
+        for (int u = 0; u < 4; ++u) {
+          own[u] = H[i + (long long)LD * (k + u)];
+          const v2d *hp = reinterpret_cast<const v2d *>(H + jb + (long long)LD * (k + u));  // L[jb + c][k + u]
+#pragma unroll
+          for (int c = 0; c < XB / 2; ++c) pan[u][c] = hp[c];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+          for (int c = 0; c < XB; c += 2) {
+            sacc[c] -= own[u] * pan[u][c >> 1][0];
+            sacc[c + 1] -= own[u] * pan[u][c >> 1][1];
+          }
+        }
       }
-      for (; k < j; ++k) s_ -= own[(long long)LD * k] * piv[k];
-      if (i == j) s_piv = s_;
+      if (i < jb + XB) {
+#pragma unroll
+        for (int c = 0; c < XB; ++c) s_dblk[i - jb][c] = sacc[c];
+      }
+    }
+    if (tid == 0) s_fail = XB;
+    __syncthreads();
+    if (wave == 0) {
+      // lane = row of the block, the row in registers; column c: the pivot and the finished column travel by
+      // v_readlane.  Right-looking inside the block: entry (row, c2) sees the subtractions k = jb, jb + 1, ...
+      // in dpotf2's order.  Lanes >= 16 compute on zeros.
+      double rv[XB];
+#pragma unroll
+      for (int c = 0; c < XB; ++c) rv[c] = (lane < XB) ? s_dblk[lane][c] : 0.0;
+      int fail = XB;
+      double fpiv = 0.0;
+#pragma unroll
+      for (int c = 0; c < XB; ++c) {
+        if (fail == XB) {
+          const double piv = lane_bcast(rv[c], c);
+          if (!(piv > 0.0)) {
+            fail = c;
+            fpiv = piv;
+          } else {
+            const double lcc = sqrt(piv);
+            const double l = (lane == c) ? lcc : rv[c] / lcc;
+            rv[c] = l;
+#pragma unroll
+            for (int c2 = c + 1; c2 < XB; ++c2) {
+              const double lc2 = lane_bcast(l, c2);  // L[c2][c]
+              if (lane > c) rv[c2] -= l * lc2;
+            }
+          }
+        }
+      }
+      if (lane < XB) {
+#pragma unroll
+        for (int c = 0; c < XB; ++c) s_dblk[lane][c] = rv[c];
+      }
+      if (lane == 0 && fail < XB) {
+        s_fail = fail;
+        s_piv = fpiv;
+      }
     }
     __syncthreads();
-    const double ajj = s_piv;
-    if (!(ajj > 0.0)) {  // info != 0: stop, go on with whatever is in H (update.cpp:183-185 only logs)
+    const int ncol = s_fail;  // columns of this panel that are final
+    if (act) {
+      if (i >= jb + XB) {  // below the block: L[i][jb + c] = (S[i][c] - sum_{c' < c} L[i][jb + c'] L[jb + c][jb + c']) / L_cc
+#pragma unroll
+        for (int c = 0; c < XB; ++c) {
+          if (c < ncol) {
+            const double l = sacc[c] / s_dblk[c][c];
+            sacc[c] = l;
+#pragma unroll
+            for (int c2 = c + 1; c2 < XB; ++c2) sacc[c2] -= l * s_dblk[c2][c];
+          }
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < XB; ++c) sacc[c] = s_dblk[i - jb][c];
+      }
+#pragma unroll
+      for (int c = 0; c < XB; ++c) {
+        if (c < ncol && i >= jb + c) {
+          H[i + (long long)LD * (jb + c)] = sacc[c];
+          if (i > jb + c) H[jb + c + (long long)LD * i] = sacc[c];  // transposed copy: contiguous in c
+        }
+      }
+    }
+    if (ncol < XB) {  // info != 0: stop, go on with whatever is in H
       if (tid == 0) {
-        H[j + LD * j] = ajj;
-        s_info = j + 1;
+        H[(jb + ncol) + (long long)LD * (jb + ncol)] = s_piv;
+        s_info = jb + ncol + 1;
       }
       break;
-    }
-    const double ljj = sqrt(ajj);
-    if (i == j) {
-      H[j + LD * j] = ljj;
-    } else if (i < r) {
-      const double lij = s_ / ljj;
-      H[i + LD * j] = lij;
-      H[j + (long long)LD * i] = lij;
     }
     __threadfence_block();
     __syncthreads();
@@ -1116,26 +992,44 @@ __device__ __attribute__((noinline)) void update_body_huge(const UpdateArgs &a, 
   T *fac = static_cast<T *>(a.factor) + (long long)I * col;
   const bool first = (iters == 1);
   double t3 = 0.0;
-  for (int i = tid; i < I; i += UPD_THREADS) {
-    T *x = fac + i;  // row i: x[c] at x[I * c]
+  // TWO rows per thread (i and i + 256): every L entry a thread fetches serves both, and a mode of 257..512 rows
+  // (C3: 300) takes one pass instead of two.  Row slot 1 of a thread without a second row computes on zeros.
+  constexpr int NR = 2;
+  for (int i0 = tid; i0 < I; i0 += NR * UPD_THREADS) {
+    T *x[NR];
+    bool ok[NR];
+#pragma unroll
+    for (int n = 0; n < NR; ++n) {
+      ok[n] = i0 + n * UPD_THREADS < I;
+      x[n] = fac + (ok[n] ? i0 + n * UPD_THREADS : i0);  // row: x[n][I * c]
+    }
     if (solved) {
-      if (i != jkf)
-        t3 += rowdot[i];
-      else
-        for (int c = 0; c < r; ++c) x[(long long)I * c] = (T)((double)x[(long long)I * c] * 0.0);
+#pragma unroll
+      for (int n = 0; n < NR; ++n) {
+        const int i = i0 + n * UPD_THREADS;
+        if (!ok[n]) continue;
+        if (i != jkf)
+          t3 += rowdot[i];
+        else
+          for (int c = 0; c < r; ++c) x[n][(long long)I * c] = (T)((double)x[n][(long long)I * c] * 0.0);
+      }
       continue;
     }
     // B := B * inv(L^T)
     for (int kb = 0; kb < rp; kb += XB) {
-      double xb[XB];
+      double xb[NR][XB];
 #pragma unroll
-      for (int c = 0; c < XB; ++c) xb[c] = (kb + c < r) ? (double)x[(long long)I * (kb + c)] : 0.0;
+      for (int n = 0; n < NR; ++n)
+#pragma unroll
+        for (int c = 0; c < XB; ++c)
+          xb[n][c] = (ok[n] && kb + c < r) ? (double)x[n][(long long)I * (kb + c)] : 0.0;
       for (int k = 0; k < kb; k += 4) {  // kb is a multiple of 16: whole batches; four columns' loads in flight
-        double xk[4];
+        double xk[NR][4];
         v2d h[4][XB / 2];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          xk[u] = (double)x[(long long)I * (k + u)];
+#pragma unroll
+          for (int n = 0; n < NR; ++n) xk[n][u] = ok[n] ? (double)x[n][(long long)I * (k + u)] : 0.0;
           const v2d *hp = reinterpret_cast<const v2d *>(H + kb + (long long)LD * (k + u));  // L[kb + c][k + u]
 #pragma unroll
           for (int c = 0; c < XB / 2; ++c) h[u][c] = hp[c];
@@ -1144,44 +1038,61 @@ __device__ __attribute__((noinline)) void update_body_huge(const UpdateArgs &a, 
         for (int u = 0; u < 4; ++u) {
 #pragma unroll
           for (int c = 0; c < XB; c += 2) {
-            xb[c] -= h[u][c >> 1][0] * xk[u];
-            xb[c + 1] -= h[u][c >> 1][1] * xk[u];
+#pragma unroll
+            for (int n = 0; n < NR; ++n) {
+              xb[n][c] -= h[u][c >> 1][0] * xk[n][u];
+              xb[n][c + 1] -= h[u][c >> 1][1] * xk[n][u];
+            }
           }
         }
       }
 #pragma unroll
       for (int k = 0; k < XB; ++k) {
-        const double xk = dinv[kb + k] * xb[k];
-        xb[k] = xk;
+        double xk[NR];
+#pragma unroll
+        for (int n = 0; n < NR; ++n) {
+          xk[n] = dinv[kb + k] * xb[n][k];
+          xb[n][k] = xk[n];
+        }
         const v2d *hp = reinterpret_cast<const v2d *>(H + kb + (long long)LD * (kb + k));  // L[kb + c][kb + k]
 #pragma unroll
         for (int c = (k + 1) & ~1; c < XB; c += 2) {
-          const v2d h = hp[c >> 1];
-          if (c > k) xb[c] -= h[0] * xk;
-          xb[c + 1] -= h[1] * xk;
+          const v2d hh = hp[c >> 1];
+#pragma unroll
+          for (int n = 0; n < NR; ++n) {
+            if (c > k) xb[n][c] -= hh[0] * xk[n];
+            xb[n][c + 1] -= hh[1] * xk[n];
+          }
         }
       }
-      if (i != jkf) {
 #pragma unroll
-        for (int c = 0; c < XB; ++c) t3 += xb[c] * xb[c];  // padding columns hold exact zeros
+      for (int n = 0; n < NR; ++n) {
+        if (ok[n] && i0 + n * UPD_THREADS != jkf) {
+#pragma unroll
+          for (int c = 0; c < XB; ++c) t3 += xb[n][c] * xb[n][c];  // padding columns hold exact zeros
+        }
+#pragma unroll
+        for (int c = 0; c < XB; ++c)
+          if (ok[n] && kb + c < r) x[n][(long long)I * (kb + c)] = (T)xb[n][c];
       }
-#pragma unroll
-      for (int c = 0; c < XB; ++c)
-        if (kb + c < r) x[(long long)I * (kb + c)] = (T)xb[c];
     }
     // B := B * inv(L)
     for (int jb = rp - XB; jb >= 0; jb -= XB) {
-      double xb[XB];
+      double xb[NR][XB];
 #pragma unroll
-      for (int c = 0; c < XB; ++c) xb[c] = (jb + c < r) ? (double)x[(long long)I * (jb + c)] : 0.0;
-      // columns jb + 16 .. rp - 1 in batches of four (the padding columns hold x = 0 and L = identity rows:
-      // they are skipped by reading x as 0 there)
+      for (int n = 0; n < NR; ++n)
+#pragma unroll
+        for (int c = 0; c < XB; ++c)
+          xb[n][c] = (ok[n] && jb + c < r) ? (double)x[n][(long long)I * (jb + c)] : 0.0;
+      // columns jb + 16 .. rp - 1 in batches of four (the padding columns: x = 0 against identity rows)
       for (int k = jb + XB; k < rp; k += 4) {
-        double xk[4];
+        double xk[NR][4];
         v2d h[4][XB / 2];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          xk[u] = (k + u < r) ? (double)x[(long long)I * (k + u)] : 0.0;
+#pragma unroll
+          for (int n = 0; n < NR; ++n)
+            xk[n][u] = (ok[n] && k + u < r) ? (double)x[n][(long long)I * (k + u)] : 0.0;
           const v2d *hp = reinterpret_cast<const v2d *>(H + jb + (long long)LD * (k + u));  // L[k + u][jb + c], transposed copy
 #pragma unroll
           for (int c = 0; c < XB / 2; ++c) h[u][c] = hp[c];
@@ -1190,26 +1101,38 @@ __device__ __attribute__((noinline)) void update_body_huge(const UpdateArgs &a, 
         for (int u = 0; u < 4; ++u) {
 #pragma unroll
           for (int c = 0; c < XB; c += 2) {
-            xb[c] -= h[u][c >> 1][0] * xk[u];
-            xb[c + 1] -= h[u][c >> 1][1] * xk[u];
+#pragma unroll
+            for (int n = 0; n < NR; ++n) {
+              xb[n][c] -= h[u][c >> 1][0] * xk[n][u];
+              xb[n][c + 1] -= h[u][c >> 1][1] * xk[n][u];
+            }
           }
         }
       }
 #pragma unroll
       for (int j = XB - 1; j >= 0; --j) {
-        double s_ = xb[j];
+        double s_[NR];
+#pragma unroll
+        for (int n = 0; n < NR; ++n) s_[n] = xb[n][j];
         const v2d *hp = reinterpret_cast<const v2d *>(H + jb + (long long)LD * (jb + j));  // L[jb + k][jb + j]
 #pragma unroll
         for (int k = (j + 1) & ~1; k < XB; k += 2) {
-          const v2d h = hp[k >> 1];
-          if (k > j) s_ -= h[0] * xb[k];
-          s_ -= h[1] * xb[k + 1];
+          const v2d hh = hp[k >> 1];
+#pragma unroll
+          for (int n = 0; n < NR; ++n) {
+            if (k > j) s_[n] -= hh[0] * xb[n][k];
+            s_[n] -= hh[1] * xb[n][k + 1];
+          }
         }
-        xb[j] = dinv[jb + j] * s_;
+#pragma unroll
+        for (int n = 0; n < NR; ++n) xb[n][j] = dinv[jb + j] * s_[n];
       }
 #pragma unroll
-      for (int c = 0; c < XB; ++c)
-        if (jb + c < r) x[(long long)I * (jb + c)] = (T)((i == jkf) ? xb[c] * 0.0 : xb[c]);
+      for (int n = 0; n < NR; ++n)
+#pragma unroll
+        for (int c = 0; c < XB; ++c)
+          if (ok[n] && jb + c < r)
+            x[n][(long long)I * (jb + c)] = (T)((i0 + n * UPD_THREADS == jkf) ? xb[n][c] * 0.0 : xb[n][c]);
     }
   }
   t3 = wave_sum(t3);
@@ -1334,11 +1257,11 @@ __global__ void __launch_bounds__(UPD_THREADS, 1) update_kernel(const UpdateArgs
   const int slot = a.slots[blockIdx.x];
   const int r = a.mt.rank[slot];
   if (r > CALS_RMAX) {
-    update_body_huge<T>(a, slot, r, sh);
+    update_body_huge<T, false>(a, slot, r, sh);
     return;
   }
   if (r > CALS_RFAST) {
-    update_body_big<T>(a, slot, r, sh);
+    update_body_huge<T, true>(a, slot, r, sh);
     return;
   }
   if (a.xld > 0) {  // the panel fits in LDS next to UpdShared (update_launch decides)
@@ -1519,8 +1442,8 @@ hipError_t update_launch(const UpdateArgs &a_in, int rmax_needed, hipStream_t st
   dyn = (dyn + 15) / 16 * 16;
   const size_t budget = (size_t)160 * 1024 - sizeof(UpdShared) - 1024;
   static const bool no_lds = getenv("CALS_UPDATE_NO_LDS") != nullptr;  // A/B switch
-  // ranks 33..64 in flight: update_body_big needs H (64 x 64) + 4 partial tiles in dynamic LDS
-  const size_t big = (rmax_needed > CALS_RFAST) ? (size_t)(CALS_RMAX * CALS_RMAX + UPD_WAVES * 256) * sizeof(double) : 0;
+  // ranks 33..64 in flight: update_body_huge<T, true> keeps H (64 columns, ld 66) + 4 partial tiles in dynamic LDS
+  const size_t big = (rmax_needed > CALS_RFAST) ? (size_t)(UPD_HLDS_LD * CALS_RMAX + UPD_WAVES * 256) * sizeof(double) : 0;
   if (dyn <= budget && !no_lds) {
     a.xld = xld;
   } else {

@@ -37,7 +37,7 @@ def main():
     for um, name in ((0, "unconstrained"), (1, "NNLS")):
         t0 = run(modes, small + [20], X, um, sweeps)
         print("%-13s 256 models of ranks 1..20: %.2f ms per sweep" % (name, t0), flush=True)
-        for r in (65, 100, 128, 256):
+        for r in [int(v) for v in sys.argv[2:]] or (65, 100, 128, 256):
             t = run(modes, small + [r], X, um, sweeps)
             print("%-13s 255 small + one rank-%-3d model: %.2f ms per sweep (+%.2f ms)" % (name, r, t, t - t0), flush=True)
 
