@@ -760,9 +760,11 @@ int sweep_once(cals_hip_engine *e, bool evict_enabled, bool defer_changed = fals
   }
   int rank_max = 1;  // sizes the update kernel's LDS panel
   size_t n_huge = 0;  // models above CALS_RMAX: the update needs a global H / L block each
+  unsigned rank_classes = 0;  // which LDS size classes of the NNLS kernel are in flight
   for (auto t : e->registry) {
     rank_max = std::max(rank_max, (int)e->models[t].rank);
     if (e->models[t].rank > CALS_RMAX) n_huge++;
+    rank_classes |= 1u << nnls_rank_class((int)e->models[t].rank);
   }
   if (n_huge) {
     if (e->prm.update_method == 1) {  // nnls_huge_kernel: H and the waves' Cholesky factors, per workgroup
@@ -851,6 +853,7 @@ int sweep_once(cals_hip_engine *e, bool evict_enabled, bool defer_changed = fals
       q.rowdot = e->rowdot;
       q.status = e->d_nnls_status;
       q.rmax = rank_max;
+      q.rank_classes = rank_classes;
       q.hscratch = e->nnls_hscratch;
       q.hcounter = e->d_hcounter;
       HIPCHK(nnls_launch(q, e->stream));

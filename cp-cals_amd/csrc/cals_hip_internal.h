@@ -175,11 +175,14 @@ struct NnlsArgs {
   double *rowdot;      // out: [n_slots][I]
   int *status;         // sticky OR: 1 Cholesky failure in the main loop, 2 exchange bound reached
   int rmax;            // largest rank in flight (sizes the LDS tiles)
+  unsigned rank_classes;  // bit k: a model of nnls_rank_class k is in flight (0: one launch sized by rmax)
+  int rlo, rhi;        // set by nnls_launch: the ranks this launch serves
   int chunks;          // set by nnls_launch: workgroups per model
   double *hscratch;    // models above CALS_RMAX: n_huge * nnls_huge_chunks(I) blocks of nnls_huge_block_doubles()
   int *hcounter;       // zero at launch: blocks are handed out in arrival order
 };
 hipError_t nnls_launch(const NnlsArgs &a, hipStream_t st);
+int nnls_rank_class(int r);  // 0: <= 24, 1: <= 32, 2: <= 48, 3: <= 64, 4: above (nnls_huge_kernel)
 size_t nnls_huge_block_doubles();
 int nnls_huge_chunks(int I);
 struct NnlsResetArgs {
