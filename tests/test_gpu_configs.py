@@ -300,3 +300,56 @@ def test_c5_all_2048_models_on_one_engine(cc, inputs):
         keep = np.arange(MODES[0]) != fiber
         slow = np.linalg.norm((X3 - R3)[keep])
         assert abs(g.error - slow) <= 1e-9 * slow
+
+
+def test_tensor_with_more_than_2_31_elements(cc):
+    """Maximum sizes: 1300 x 1290 x 1310 fp64 = 2.197e9 elements (17.6 GB; the reference's device path takes an
+    `int size`, src/cuda_utils.cpp:57 -- SURVEY 8c).  No oracle at this size, exact identities instead: an all-ones
+    rank-1 model's MTTKRP columns are the mode sums of X; one column per mode against tensordot; ||X||; and after
+    two sweeps under the engine's own plan the fast error of a model equals ||X - reconstruction|| computed slab
+    by slab.  Non-cubic so that swapped strides cannot cancel."""
+    modes = [1300, 1290, 1310]
+    n = int(np.prod(modes))
+    assert n > 2 ** 31
+    rng = np.random.default_rng(5)
+    X = rng.random(n)
+    X *= 2.0
+    X -= 1.0
+    X3 = X.reshape(modes, order="F")
+    ranks = [1, 3, 4]
+    frng = np.random.default_rng(6)
+    models, facs = [], []
+    for k, r in enumerate(ranks):
+        fs = [np.asfortranarray(frng.uniform(-1, 1, size=(I, r))) for I in modes]
+        if k == 0:
+            fs = [np.ones((I, 1), order="F") for I in modes]
+        lam = np.ones(r)
+        models.append(cc.Model([f.copy(order="F") for f in fs], lam))
+        facs.append(fs)
+    e = cc.Engine(modes, sum(ranks))
+    e.set_tensor(X)
+    for m in models:
+        e.enqueue(m)
+    assert e.admit() == len(ranks)
+    G = [e.debug_mttkrp(nm, "plain") for nm in range(3)]
+    assert rel(G[0][:, 0], X3.sum(axis=(1, 2))) < 1e-11
+    assert rel(G[1][:, 0], X3.sum(axis=(0, 2))) < 1e-11
+    assert rel(G[2][:, 0], X3.sum(axis=(0, 1))) < 1e-11
+    a, b, c = (facs[2][nm][:, 1] for nm in range(3))       # column 5 of the buffer = column 1 of model 2
+    t_ab = np.tensordot(X3, c, axes=([2], [0]))              # I x J
+    assert rel(G[0][:, 5], t_ab @ b) < 1e-11
+    assert rel(G[1][:, 5], t_ab.T @ a) < 1e-11
+    del t_ab
+    assert rel(G[2][:, 5], np.tensordot(np.tensordot(X3, a, axes=([0], [0])), b, axes=([0], [0]))) < 1e-11
+    e.set_params(cc.default_params(max_iterations=2, force_max_iter=1))
+    rep = e.run()
+    e.close()
+    assert abs(rep.X_norm - np.sqrt(np.dot(X, X))) <= 1e-12 * rep.X_norm
+    m = models[2]
+    A, B, C_ = m.factors
+    err2 = 0.0
+    AL = A * m.lam
+    for k in range(modes[2]):                                 # slab k: X[:, :, k] - (A diag(lam) diag(C[k])) B^T
+        d = X3[:, :, k] - (AL * C_[k]) @ B.T
+        err2 += float(np.vdot(d, d))
+    assert abs(m.error - np.sqrt(err2)) <= 1e-9 * np.sqrt(err2)
