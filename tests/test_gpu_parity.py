@@ -353,3 +353,37 @@ def test_full_size_c2_fast_error_is_true_error(cc, inputs):
     for m in gm[::7]:
         slow = np.linalg.norm(X - reconstruct(m.factors, m.lam, modes))
         assert abs(m.error - slow) <= 1e-9 * slow
+
+
+# ---- edges of the input domain ----
+@pytest.mark.parametrize("modes,ranks", [
+    ([3, 2, 3, 2, 2, 3, 2, 2], [2, 3]),      # 8-way: CALS_HIP_MAX_MODES
+    ([7, 1, 5], [2, 1]),                      # a mode of size 1
+    ([1, 1, 9], [1]),                         # a fibre
+    ([17, 16, 15], [17 * 2]),                 # rank above every mode size (singular Hadamard of Gramians is possible)
+])
+def test_edge_shapes_vs_oracle(cc, oracle, inputs, modes, ranks):
+    X = inputs.tensor(modes, 9)
+    gm, om, rep, ro = _run_both(cc, oracle, inputs, modes, ranks, X, 4)
+    assert rep.iter == ro.iter == 4
+    for a, b in zip(gm, om):
+        assert a.iters == b.iters
+        # the rank-deficient cases are compared through the fitted tensor: individual columns of a singular system
+        # are not determined
+        d = np.linalg.norm(reconstruct(a.factors, a.lam, modes) - reconstruct(b.factors, b.lam, modes))
+        assert d <= 1e-7 * max(1.0, np.linalg.norm(X))
+
+
+def test_empty_queue_and_exact_fit_of_the_buffer(cc, oracle, inputs):
+    modes = [9, 8, 7]
+    X = inputs.tensor(modes, 2)
+    e = cc.Engine(modes, 12)
+    e.set_tensor(X)
+    e.set_params(cc.default_params(max_iterations=5, force_max_iter=1))
+    rep = e.run()                                      # nothing queued: returns at once
+    assert (rep.iter, rep.n_ktensors) == (0, 0)
+    e.close()
+    # models whose ranks fill the buffer to the last column, then a queue that needs it twice over
+    gm, om, rep, ro = _run_both(cc, oracle, inputs, modes, [5, 4, 3, 12, 6, 6], X, 5, buffer=12)
+    assert (rep.iter, rep.n_ktensors, rep.ktensor_comp_sum) == (ro.iter, ro.n_ktensors, ro.ktensor_comp_sum)
+    _assert_models_match(gm, om, ro.X_norm ** 2)
