@@ -387,3 +387,33 @@ def test_empty_queue_and_exact_fit_of_the_buffer(cc, oracle, inputs):
     gm, om, rep, ro = _run_both(cc, oracle, inputs, modes, [5, 4, 3, 12, 6, 6], X, 5, buffer=12)
     assert (rep.iter, rep.n_ktensors, rep.ktensor_comp_sum) == (ro.iter, ro.n_ktensors, ro.ktensor_comp_sum)
     _assert_models_match(gm, om, ro.X_norm ** 2)
+
+
+def test_a_singular_model_does_not_disturb_its_neighbours(cc, oracle, inputs):
+    """Models whose columns are all equal have a singular Hadamard of Gramians: dpotrf reports info > 0 (the
+    reference only logs, update.cpp:183-185) or factors a numerically meaningless matrix.  Whatever such a model
+    ends up holding, the run terminates and the healthy models in the same buffer -- one per update body: register /
+    LDS, blocked in LDS, blocked through L2 -- are exactly what they are without it."""
+    modes = [30, 25, 20]
+    X = inputs.tensor(modes, 4)
+    good_ranks = [5, 12, 40, 70]
+    base = make_models(inputs, modes, good_ranks, seed=3)
+    bad = []
+    for r in (20, 40, 70):
+        (fs, lam), = inputs.model_factors(modes, [1], seed=50 + r)
+        bad.append(([np.asfortranarray(np.repeat(f, r, axis=1)) for f in fs], np.ones(r)))
+    e = cc.Engine(modes, sum(good_ranks) + 130)
+    e.set_tensor(X)
+    e.set_params(cc.default_params(max_iterations=4, force_max_iter=1))
+    gm = [cc.Model([f.copy() for f in fs], lam.copy()) for fs, lam, _ in base]
+    bm = [cc.Model(fs, lam) for fs, lam in bad]
+    for m in (gm[0], bm[0], gm[1], bm[1], gm[2], bm[2], gm[3]):
+        e.enqueue(m)
+    with np.errstate(all="ignore"):
+        rep = e.run()
+    e.close()
+    assert rep.iter == 4 and rep.n_ktensors == 7
+    om = [oracle.Model(fs, lam) for fs, lam, _ in base]
+    ro = oracle.cp_cals(X, modes, om, oracle.default_params(max_iterations=4, force_max_iter=1,
+                                                            mttkrp_method=oracle.MTTKRP, buffer_size=sum(good_ranks)))
+    _assert_models_match(gm, om, ro.X_norm ** 2)
