@@ -1419,7 +1419,7 @@ int cals_hip_create_ex(cals_hip_engine **out, int n_modes, const int64_t *modes,
       const int mt = (tiles + mb - 1) / mb;
       const double S = (double)modes[second];
       const double ttm = 2.0 * Mp * round_up((int)modes[a_mode], 16) * S / (peak * eff(mt) * 0.95);
-      return ttm + (double)Mp * S * (double)e->es / 3.5e12;
+      return ttm + (double)Mp * S * (double)e->es / 6.0e12;  // contract4_kernel streams T at 6.2-6.3 TB/s
     };
     auto t_bytes = [&](int first) {
       return (size_t)buffer_size * (size_t)modes[(first + 1) % 3] *
@@ -1427,8 +1427,10 @@ int cals_hip_create_ex(cals_hip_engine **out, int n_modes, const int64_t *modes,
     };
     const double c_plain = plain_cost(0) + plain_cost(1) + plain_cost(2);
     const double cost[4] = {c_plain, pair_cost(0) + plain_cost(2), pair_cost(1) + plain_cost(0),
-                            // multi-sweep: 3 pairs per 2 sweeps, + 10 % for T's lost to line search
-                            0.55 * (pair_cost(0) + pair_cost(1) + pair_cost(2))};
+                            // multi-sweep: 3 pairs per 2 sweeps, + 4 % for the stale columns a line search
+                            // leaves behind (patched, not recomputed).  Both constants checked against the
+                            // measured best plan of 14 shapes (tools/plan_scan.py, profiles/r02_plan_scan.txt)
+                            0.52 * (pair_cost(0) + pair_cost(1) + pair_cost(2))};
     int choice = 0;
     for (int k = 1; k < 4; k++)
       if (cost[k] < 0.97 * c_plain && cost[k] < cost[choice]) choice = k;
