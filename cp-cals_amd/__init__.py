@@ -375,7 +375,7 @@ class Engine:
         return xn.value, jk
 
     def set_profiling(self, level):
-        """0/False off, 1/True every launch, 2 MFMA kernels + contraction only (cheaper, see cals_hip.h)."""
+        """0/False off, 1/True every launch, 2 MFMA kernels + contraction only (cheaper, see cals_hip.h), 3 MFMA kernels only."""
         self._chk(self.lib.cals_hip_set_profiling(self.h, int(level)))
 
     def kernel_stats(self):

@@ -313,6 +313,7 @@ int prof_begin(cals_hip_engine *e, int cls, double flops, int kind = LOG_NONE) {
   // packets on the queue and keeps the next launch from overlapping the kernel's tail: around all 13
   // launches of a sweep that costs 62 us per sweep (23 % at C2, 1.9 % at C3; tools/profiling_cost.py).
   if (e->profiling == 2 && (cls == 1 || cls == 2)) return -1;
+  if (e->profiling == 3 && cls != 0 && cls != 3) return -1;  // level 3: the MFMA kernels only
   if (e->ev_used >= e->ev_pool.size()) {
     if (e->ev_pool.size() >= 16384) return -1;
     EventPair p;
@@ -2133,7 +2134,7 @@ int cals_hip_set_profiling(cals_hip_engine *e, int enabled) {
   if (!e) return CALS_HIP_ERR_ARG;
   HIPCHK(hipSetDevice(e->device));  // a process may hold engines on several GPUs
   if (!enabled) prof_collect(e);
-  e->profiling = enabled < 0 ? 0 : (enabled > 2 ? 2 : enabled);
+  e->profiling = enabled < 0 ? 0 : (enabled > 3 ? 3 : enabled);
   return CALS_HIP_OK;
 }
 

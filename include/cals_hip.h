@@ -248,7 +248,7 @@ int64_t cals_hip_host_active_cols(const int64_t *occupancy, int64_t n_cols);
 /* ---- measurement ---- */
 /* level: 0 off; 1 hipEvent pairs around every launch; 2 around the MFMA kernels (MTTKRP, TTM) and the
  * contraction only -- the pairs themselves cost ~5 us per launch of queue time, which matters when a
- * sweep is 13 launches of 4-40 us (BASELINE config 2). */
+ * sweep is 13 launches of 4-40 us (BASELINE config 2); 3 around the MFMA kernels only. */
 int cals_hip_set_profiling(cals_hip_engine *e, int level);
 int cals_hip_get_kernel_stats(cals_hip_engine *e, cals_hip_kernel_stats *out);
 int cals_hip_reset_kernel_stats(cals_hip_engine *e);
