@@ -328,7 +328,8 @@ class Engine:
 
     @property
     def tree(self):
-        """0 = three fused MTTKRPs per sweep, 1 = dimension tree A, 2 = tree B (cals_hip_tree)."""
+        """0 = one fused MTTKRP per mode and sweep, 1 = dimension tree A, 2 = tree B, 3 = multi-sweep tree M (3-way);
+        4 = two-group dimension tree (N > 3 modes)  (cals_hip_tree)."""
         return int(self.lib.cals_hip_tree(self.h))
 
     @property

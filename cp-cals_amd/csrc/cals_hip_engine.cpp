@@ -74,6 +74,19 @@ struct TreePlan {
   int *d_stale_idx = nullptr;
 };
 
+// Dimension tree for N > 3 modes (GroupContractArgs in cals_hip_internal.h): modes [0, h) and [h, N) are two
+// groups of adjacent modes; vl[g] is the layout of the fused MTTKRP over the tensor VIEWED with group g merged
+// into one mode (a reshape: adjacent modes, no data movement beyond the usual padded copy), contracted with the
+// other group's factors.  Two such MTTKRPs per sweep instead of N; T lives within the sweep only (the groups are
+// updated one after the other), so evictions, compress and the line search at the sweep boundary never see it.
+struct GroupPlan {
+  bool on = false;
+  int h = 0;
+  ModeLayout vl[2];
+  long long rows[2] = {0, 0};  // prod of the group's mode sizes
+  void *Tg = nullptr;          // max(rows) x capacity, element type = dtype
+};
+
 struct EventPair {
   hipEvent_t a, b;
 };
@@ -103,6 +116,7 @@ struct cals_hip_engine {
   std::vector<double> jk_norms;
   ModeLayout lay[CALS_HIP_MAX_MODES];
   TreePlan tree;
+  GroupPlan gp;
 
   int dtype = CALS_F64;  // storage type of X copies, multi-factors, partials (compute follows it)
   size_t es = sizeof(double);
@@ -455,8 +469,7 @@ size_t partial_tile_cap(const cals_hip_engine *e, size_t nb_max) {
   return std::max<size_t>((size_t)8 * e->n_cu, nb_max);
 }
 
-Geo geometry(const cals_hip_engine *e, int mode, int64_t R) {
-  const ModeLayout &L = e->lay[mode];
+Geo geometry(const cals_hip_engine *e, const ModeLayout &L, int64_t R) {
   Geo g;
   g.NB = (int)((R + CALS_BN - 1) / CALS_BN);
   const long long U = (long long)(L.Ap / 16) * L.S;
@@ -476,10 +489,10 @@ Geo geometry(const cals_hip_engine *e, int mode, int64_t R) {
 
 // fset: the factor buffers to contract with (default: the multi-factors; the error-checking line
 // search passes the extrapolated candidates)
-int launch_mttkrp(cals_hip_engine *e, int mode, int64_t R, Geo *geo_out, void *const *fset = nullptr) {
+int launch_mttkrp_layout(cals_hip_engine *e, const ModeLayout &L, int64_t R, Geo *geo_out,
+                         void *const *fset = nullptr) {
   if (!fset) fset = e->factor;
-  const ModeLayout &L = e->lay[mode];
-  const Geo g = geometry(e, mode, R);
+  const Geo g = geometry(e, L, R);
   const void *Q;
   long long ldQ;
   if (L.s_modes.size() == 1) {
@@ -534,6 +547,46 @@ int launch_mttkrp(cals_hip_engine *e, int mode, int64_t R, Geo *geo_out, void *c
   HIPCHK(mttkrp3_launch(L.MT, L.m_blocks, a, e->stream));
   prof_end(e, pk);
   if (geo_out) *geo_out = g;
+  return CALS_HIP_OK;
+}
+
+int launch_mttkrp(cals_hip_engine *e, int mode, int64_t R, Geo *geo_out, void *const *fset = nullptr) {
+  return launch_mttkrp_layout(e, e->lay[mode], R, geo_out, fset);
+}
+
+// N > 3 dimension tree: T of group g (the fused MTTKRP over the merged view + the split-K reduction)
+int launch_group_t(cals_hip_engine *e, int g, int64_t R) {
+  GroupPlan &gp = e->gp;
+  Geo geo{0, 0};
+  int rc = launch_mttkrp_layout(e, gp.vl[g], R, &geo);
+  if (rc) return rc;
+  const int pk = prof_begin(e, 2, 0, LOG_FUSED);
+  HIPCHK(reduce_partials_launch(e->partial, geo.T, gp.vl[g].ldPart, (int)gp.rows[g], (int)R, gp.Tg, e->dtype,
+                                e->stream));
+  prof_end(e, pk);
+  return CALS_HIP_OK;
+}
+
+// ... and the MTTKRP of mode n from it, written to `out` (ld = I_n)
+int launch_group_contract(cals_hip_engine *e, int n, int64_t R, void *out) {
+  const GroupPlan &gp = e->gp;
+  const int g = n < gp.h ? 0 : 1, first = g ? gp.h : 0, h = g ? e->n_modes - gp.h : gp.h;
+  GroupContractArgs a{};
+  a.T = gp.Tg;
+  a.ldT = gp.rows[g];
+  a.h = h;
+  for (int k = 0; k < h; k++) {
+    a.dims[k] = (int)e->modes[first + k];
+    a.F[k] = e->factor[first + k];
+  }
+  a.n_local = n - first;
+  a.out = out;
+  a.R = (int)R;
+  a.dtype = e->dtype;
+  const double bytes = (double)R * (double)gp.rows[g] * (double)e->es;
+  const int pk = prof_begin(e, 4, bytes, LOG_CONTRACT);
+  HIPCHK(group_contract_launch(a, e->stream));
+  prof_end(e, pk);
   return CALS_HIP_OK;
 }
 
@@ -810,9 +863,15 @@ int sweep_once(cals_hip_engine *e, bool evict_enabled, bool defer_changed = fals
       // queue the column layout changes after nearly every sweep -- eviction, compress, admission --
       // and that T would be dropped unused: the plain fused MTTKRP is the cheaper way to G then.)
       if ((rc = launch_ttm(e, n, R, &g))) return rc;
+    } else if (e->gp.on) {
+      // N > 3: the group's T at its first mode, then every mode of the group by a per-column contraction
+      if (n == 0 || n == e->gp.h)
+        if ((rc = launch_group_t(e, n ? 1 : 0, R))) return rc;
+      if ((rc = launch_group_contract(e, n, R, e->factor[n]))) return rc;
     } else if ((rc = launch_mttkrp(e, n, R, &g))) {
       return rc;
     }
+    const bool g_in_place = by_contract || e->gp.on;  // G is already in the factor buffer
     UpdateArgs u{};
     u.slots = e->d_slots;
     u.n_slots = ns;
@@ -836,7 +895,7 @@ int sweep_once(cals_hip_engine *e, bool evict_enabled, bool defer_changed = fals
     u.hcounter = e->d_hcounter;
     if (n_huge) HIPCHK(hipMemsetAsync(e->d_hcounter, 0, sizeof(int), e->stream));
     const int pk = prof_begin(e, 1, 0, LOG_UPDATE);
-    if (!by_contract)
+    if (!g_in_place)
       HIPCHK(reduce_partials_launch(e->partial, g.T, e->lay[n].ldPart, (int)e->modes[n], (int)R,
                                     e->factor[n], e->dtype, e->stream));
     if (e->prm.update_method == 1) {  // update::NNLS (cals.cpp:244-248)
@@ -1488,6 +1547,58 @@ int cals_hip_create_ex(cals_hip_engine **out, int n_modes, const int64_t *modes,
     part_rows_max = std::max<size_t>(part_rows_max, (size_t)L.ldPart * (size_t)L.m_blocks);
     if (L.s_modes.size() > 1) krp_max = std::max<size_t>(krp_max, (size_t)L.S * (size_t)buffer_size);
   }
+  // ---- N > 3: two-group dimension tree (GroupPlan); CALS_HIP_TREE=0 keeps the N fused MTTKRPs per sweep ----
+  size_t group_part_elems = 0;
+  if (n_modes >= 4 && !(getenv("CALS_HIP_TREE") && getenv("CALS_HIP_TREE")[0] == '0')) {
+    GroupPlan &gp = e->gp;
+    double best = 1e300;
+    for (int h = 2; h <= 4 && n_modes - h >= 2; h++) {
+      if (n_modes - h > 4) continue;
+      double r0 = 1.0, r1 = 1.0;
+      for (int k = 0; k < n_modes; k++) (k < h ? r0 : r1) *= (double)modes[k];
+      if (std::max(r0, r1) < best) {
+        best = std::max(r0, r1);
+        gp.h = h;
+      }
+    }
+    if (gp.h && best < 2.0e9) {
+      gp.on = true;
+      for (int g = 0; g < 2; g++) {
+        ModeLayout &L = gp.vl[g];
+        const int lo = g ? gp.h : 0, hi = g ? n_modes : gp.h;      // the group's modes
+        const int olo = g ? 0 : gp.h, ohi = g ? gp.h : n_modes;    // the other group's
+        gp.rows[g] = 1;
+        for (int k = lo; k < hi; k++) gp.rows[g] *= modes[k];
+        double waste_best = 1e30;
+        for (int k = olo; k < ohi; k++) {
+          const double waste = (double)round_up((int)modes[k], 16) / (double)modes[k];
+          if (waste < waste_best - 1e-12) {
+            waste_best = waste;
+            L.a_mode = k;
+          }
+        }
+        L.A = (int)modes[L.a_mode];
+        L.Ap = round_up(L.A, 16);
+        L.Mp = round_up((int)gp.rows[g], 16);
+        L.S = 1;
+        for (int k = olo; k < ohi; k++)
+          if (k != L.a_mode) {
+            L.s_modes.push_back(k);
+            L.S *= modes[k];
+          }
+        const int m_tiles = L.Mp / 16;
+        L.m_blocks = (m_tiles + 19) / 20;
+        L.MT = mttkrp_pick_mt((m_tiles + L.m_blocks - 1) / L.m_blocks);
+        if (L.MT == 0) return fail(e, CALS_HIP_ERR_ARG, "internal: no MTTKRP tile for this group size");
+        L.ldPart = L.m_blocks * 16 * L.MT;
+        if (L.s_modes.size() > 1) krp_max = std::max<size_t>(krp_max, (size_t)L.S * (size_t)buffer_size);
+        // partial tiles: NB * T <= partial_tile_cap / m_blocks (geometry()), or NB alone when T = 1
+        const size_t nbm = (size_t)((buffer_size + CALS_BN - 1) / CALS_BN);
+        group_part_elems = std::max(group_part_elems, (partial_tile_cap(e, nbm) / (size_t)L.m_blocks + nbm) *
+                                                          (size_t)L.ldPart * CALS_BN);
+      }
+    }
+  }
   int rc;
   for (int n = 0; n < n_modes; n++) {
     if ((rc = dev_alloc_elems(e, &e->factor[n], (size_t)(modes[n] * buffer_size)))) return rc;
@@ -1525,7 +1636,11 @@ int cals_hip_create_ex(cals_hip_engine **out, int n_modes, const int64_t *modes,
   }
   size_t ld_max = 0;
   for (int n = 0; n < n_modes; n++) ld_max = std::max<size_t>(ld_max, (size_t)e->lay[n].ldPart);
-  e->partial_elems = partial_tile_cap(e, nb_max) * ld_max * CALS_BN;
+  e->partial_elems = std::max(partial_tile_cap(e, nb_max) * ld_max * CALS_BN, group_part_elems);
+  if (e->gp.on) {
+    const size_t t_rows = (size_t)std::max(e->gp.rows[0], e->gp.rows[1]);
+    if ((rc = dev_alloc_elems(e, &e->gp.Tg, t_rows * (size_t)buffer_size))) return rc;
+  }
   if (getenv("CALS_TTM_TRACE")) {
     if ((rc = dev_alloc(e, &e->dbg_trace, (size_t)16 * 2048))) return rc;
   }
@@ -1678,6 +1793,8 @@ int cals_hip_destroy(cals_hip_engine *e) {
   fr(e->dbg_trace);
   fr(e->dbg_clock);
   fr(e->krp_ws);
+  fr(e->gp.Tg);
+  for (int g = 0; g < 2; g++) fr(e->gp.vl[g].Xp);
   fr(e->d_jk_norms);
   fr(e->mt.col);
   fr(e->mt.rank);
@@ -1731,6 +1848,33 @@ int set_tensor_impl(cals_hip_engine *e, const void *X_host, int src_dtype) {
     HIPCHK(permute_pad_launch(dX, src_dtype, e->n_modes, dims, n, L.a_mode, L.Mp, L.Ap, L.Xp,
                               e->dtype, L.S, e->stream));
   }
+  for (int g = 0; g < 2 && e->gp.on; g++) {
+    // group g merged into one mode: a 3-or-more-way VIEW of the same buffer (adjacent modes, contiguous strides)
+    ModeLayout &L = e->gp.vl[g];
+    if (L.Xp) {
+      HIPCHK(hipFree(L.Xp));
+      L.Xp = nullptr;
+    }
+    int vdims[CALS_HIP_MAX_MODES], nv = 0, vm = 0, va = 0;
+    if (g == 0) {
+      vdims[nv++] = (int)e->gp.rows[0];
+      for (int k = e->gp.h; k < e->n_modes; k++) {
+        if (k == L.a_mode) va = nv;
+        vdims[nv++] = dims[k];
+      }
+      vm = 0;
+    } else {
+      for (int k = 0; k < e->gp.h; k++) {
+        if (k == L.a_mode) va = nv;
+        vdims[nv++] = dims[k];
+      }
+      vm = nv;
+      vdims[nv++] = (int)e->gp.rows[1];
+    }
+    const size_t elems = (size_t)L.Mp * (size_t)L.Ap * (size_t)L.S;
+    HIPCHK(hipMalloc((void **)&L.Xp, elems * e->es));
+    HIPCHK(permute_pad_launch(dX, src_dtype, nv, vdims, vm, va, L.Mp, L.Ap, L.Xp, e->dtype, L.S, e->stream));
+  }
   // ||X|| and the jackknife norms from the mode-0 slice sums of squares
   const long long I = e->modes[0], cols = total / I;
   const int n_part = 256;
@@ -1767,6 +1911,7 @@ int cals_hip_set_tensor_f32(cals_hip_engine *e, const float *X_host) {
 }
 
 int cals_hip_tree(const cals_hip_engine *e) {
+  if (e && e->gp.on) return 4;
   return (e && e->tree.on) ? e->tree.kind : 0;
 }
 
@@ -1993,6 +2138,30 @@ int cals_hip_debug_mttkrp(cals_hip_engine *e, int mode, double *G_host) {
   // the path a sweep would take for this mode under the engine's plan: as `second` of a pair
   // if there is one, else as `first`, else the plain fused MTTKRP
   int path = CALS_HIP_PATH_PLAIN;
+  if (e && e->gp.on && G_host && mode >= 0 && mode < e->n_modes) {
+    // N > 3 dimension tree: the group's T from the current factors, then this mode's contraction
+    HIPCHK(hipSetDevice(e->device));
+    if (!e->has_tensor) return fail(e, CALS_HIP_ERR_STATE, "set_tensor first");
+    if (e->registry.empty()) return fail(e, CALS_HIP_ERR_STATE, "no model in flight");
+    const int64_t R = e->end, I = e->modes[mode];
+    int rc = launch_group_t(e, mode < e->gp.h ? 0 : 1, R);
+    if (rc) return rc;
+    void *scratch = nullptr;
+    HIPCHK(hipMalloc(&scratch, (size_t)(I * R) * e->es));
+    rc = launch_group_contract(e, mode, R, scratch);
+    if (rc) {
+      (void)hipFree(scratch);
+      return rc;
+    }
+    std::vector<float> hf;
+    if (e->dtype == CALS_F32) hf.resize((size_t)(I * R));
+    HIPCHK(hipMemcpyAsync(e->dtype == CALS_F32 ? (void *)hf.data() : (void *)G_host, scratch,
+                          (size_t)(I * R) * e->es, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    for (size_t i = 0; i < hf.size(); i++) G_host[i] = (double)hf[i];
+    HIPCHK(hipFree(scratch));
+    return CALS_HIP_OK;
+  }
   if (e && e->tree.on && mode >= 0 && mode < 3) {
     if (e->tree.pair[(mode + 2) % 3].on) path = CALS_HIP_PATH_SECOND;
     else if (e->tree.pair[mode].on) path = CALS_HIP_PATH_FIRST;

@@ -203,6 +203,24 @@ hipError_t stale_cols_launch(const int *slots, int n, const ModelTable &mt, int 
 // desc: n x {slot, col, rank, jk_mode, jk_fiber}
 hipError_t init_slots_launch(const int *desc, int n, const ModelTable &mt, hipStream_t st);
 
+// Dimension tree for N > 3 modes: the modes are split into two groups of adjacent modes; one fused MTTKRP per
+// group over the tensor viewed as (group, other modes...) gives T[(i_0 .. i_{h-1}), c] = the tensor contracted
+// with the OTHER group's factors, column by column; the MTTKRP of a mode of the group is then a small
+// per-column contraction of T with the remaining factors of the group:
+//   out[i_n, c] = sum_{i_k, k != n} T[i_0 + d_0 (i_1 + d_1 (...)), c] * prod_{k != n} F_k[i_k, c]
+struct GroupContractArgs {
+  const void *T;        // [rows = prod d_k] x R, ld = ldT, element type = dtype
+  long long ldT;
+  int h;                // modes in the group (2 .. 4)
+  int dims[4];
+  int n_local;          // the mode (position in the group) the result belongs to
+  const void *F[4];     // factors of the group's modes (F[n_local] unused), ld = dims[k]
+  void *out;            // dims[n_local] x R, ld = dims[n_local]
+  int R;
+  int dtype;
+};
+hipError_t group_contract_launch(const GroupContractArgs &a, hipStream_t st);
+
 // Gramians of all modes for freshly admitted models (MultiKtensor::add, multi_ktensor.cpp:88-94)
 struct GramInitArgs {
   const int *slots;

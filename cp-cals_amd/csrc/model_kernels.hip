@@ -1471,6 +1471,85 @@ hipError_t update_launch(const UpdateArgs &a_in, int rmax_needed, hipStream_t st
 }
 
 // ---------------------------------------------------------------------------------------------
+// group_contract_kernel (N > 3 dimension tree, see GroupContractArgs): one workgroup per column.
+// n_local == 0: thread = i_0 (coalesced over T's fastest index), the other indices in a serial loop;
+// n_local > 0: wave = one i_n at a time, lanes over i_0, the remaining indices serial, a wave butterfly at the
+// end.  Fixed summation order; HBM / L2 bound (T is read once per mode of its group).
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) group_contract_kernel(const GroupContractArgs a) {
+  const int c = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const T *Tc = static_cast<const T *>(a.T) + a.ldT * c;
+  const T *F[4];
+  for (int k = 0; k < a.h; ++k) F[k] = static_cast<const T *>(a.F[k]) + (long long)a.dims[k] * c;
+  T *out = static_cast<T *>(a.out) + (long long)a.dims[a.n_local] * c;
+  const int d0 = a.dims[0];
+  long long rest_total = 1;  // combinations of the indices 1 .. h-1
+  for (int k = 1; k < a.h; ++k) rest_total *= a.dims[k];
+  if (a.n_local == 0) {
+    for (int i0 = tid; i0 < d0; i0 += 256) {
+      double acc = 0.0;
+      for (long long rest = 0; rest < rest_total; ++rest) {
+        long long q = rest;
+        double w = 1.0;
+        for (int k = 1; k < a.h; ++k) {
+          w *= (double)F[k][q % a.dims[k]];
+          q /= a.dims[k];
+        }
+        acc += (double)Tc[i0 + (long long)d0 * rest] * w;
+      }
+      out[i0] = (T)acc;
+    }
+    return;
+  }
+  const int n = a.n_local, dn = a.dims[n];
+  long long below = 1, above = 1;  // products of the dims between 0 and n, and above n
+  for (int k = 1; k < n; ++k) below *= a.dims[k];
+  for (int k = n + 1; k < a.h; ++k) above *= a.dims[k];
+  for (int in = wave; in < dn; in += 4) {
+    double acc = 0.0;
+    for (long long hi = 0; hi < above; ++hi) {
+      double whi = 1.0;
+      {
+        long long q = hi;
+        for (int k = n + 1; k < a.h; ++k) {
+          whi *= (double)F[k][q % a.dims[k]];
+          q /= a.dims[k];
+        }
+      }
+      for (long long lo = 0; lo < below; ++lo) {
+        double w = whi;
+        {
+          long long q = lo;
+          for (int k = 1; k < n; ++k) {
+            w *= (double)F[k][q % a.dims[k]];
+            q /= a.dims[k];
+          }
+        }
+        const long long rest = lo + below * (in + (long long)dn * hi);
+        const T *row = Tc + (long long)d0 * rest;
+        double part = 0.0;
+        for (int i0 = lane; i0 < d0; i0 += 64) part += (double)row[i0] * (double)F[0][i0];
+        acc += part * w;
+      }
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) out[in] = (T)acc;
+  }
+}
+
+hipError_t group_contract_launch(const GroupContractArgs &a, hipStream_t st) {
+  if (a.R <= 0) return hipSuccess;
+  if (a.h < 2 || a.h > 4 || a.n_local < 0 || a.n_local >= a.h) return hipErrorInvalidValue;
+  if (a.dtype == CALS_F32)
+    hipLaunchKernelGGL(group_contract_kernel<float>, dim3(a.R), dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL(group_contract_kernel<double>, dim3(a.R), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
 // Gramians at admission (MultiKtensor::add, src/multi_ktensor.cpp:88-94)
 // ---------------------------------------------------------------------------------------------
 template <typename T>

@@ -144,7 +144,12 @@ int cals_hip_dtype(const cals_hip_engine *e);
  * share X x_0 A; 3 ("M", multi-sweep) = every TTM serves two consecutive updates of the sequence
  * A B C A B C ..., also across the sweep boundary (3 TTMs per 2 sweeps); a T that a line-search
  * step, an eviction or an admission made stale is dropped and recomputed.  Chosen by a cost model;
- * CALS_HIP_TREE=0|A|B|M in the environment at create overrides it. */
+ * CALS_HIP_TREE=0|A|B|M in the environment at create overrides it.
+ * N > 3 modes: 4 = two-group dimension tree -- modes [0, h) and [h, N) are merged into one mode each (adjacent
+ * modes: a reshape), one fused MTTKRP per group against the other group's factors gives T_group, and every mode
+ * of the group comes from a per-column contraction of T_group with the group's other factors: 2 MTTKRP-sized
+ * contractions per sweep instead of N (the reference runs one Khatri-Rao + GEMM per mode, mttkrp.cpp:147-176,
+ * 218-328).  CALS_HIP_TREE=0 keeps the N fused MTTKRPs. */
 int cals_hip_tree(const cals_hip_engine *e);
 /* Re-targets an IDLE engine (nothing queued or in flight) at another buffer_size <= the capacity it
  * was created with: same tensor copies in HBM, same plan, same device buffers, fresh packing state

@@ -108,6 +108,7 @@ hipError_t contract_launch(const void *, long long, int, int, const void *, long
   return hipSuccess;
 }
 hipError_t krp_launch(const KrpArgs &, hipStream_t) { return hipSuccess; }
+hipError_t group_contract_launch(const GroupContractArgs &, hipStream_t) { return hipSuccess; }
 hipError_t update_launch(const UpdateArgs &, int, hipStream_t) { return hipSuccess; }
 hipError_t nnls_launch(const NnlsArgs &, hipStream_t) { return hipSuccess; }
 int nnls_rank_class(int r) { return r <= 24 ? 0 : r <= 32 ? 1 : r <= 48 ? 2 : r <= CALS_RMAX ? 3 : 4; }

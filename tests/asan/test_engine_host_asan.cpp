@@ -164,6 +164,32 @@ static void stepwise_api() {
   CHECK(cals_hip_destroy(e) == CALS_HIP_OK);
 }
 
+// N > 3: the two-group dimension tree's host side (virtual layouts, Khatri-Rao workspace of a 3- and a 4-mode
+// outer group, T and partial-tile sizing) for every N up to the maximum
+static void n_way_group_tree() {
+  for (const std::vector<int64_t> &modes : {std::vector<int64_t>{5, 4, 3, 6, 2}, std::vector<int64_t>{3, 4, 2, 3, 2, 4},
+                                            std::vector<int64_t>{2, 3, 2, 3, 2, 3, 2}, std::vector<int64_t>{3, 2, 3, 2, 2, 3, 2, 2},
+                                            std::vector<int64_t>{40, 33, 6, 50}}) {
+    cals_hip_engine *e = nullptr;
+    CHECK(cals_hip_create(&e, (int)modes.size(), modes.data(), 300, 0) == CALS_HIP_OK);
+    CHECK(cals_hip_tree(e) == 4);
+    size_t total = 1;
+    for (auto d : modes) total *= (size_t)d;
+    std::vector<double> X(total, 0.25);
+    CHECK(cals_hip_set_tensor(e, X.data()) == CALS_HIP_OK);
+    auto models = make_models(modes, {5, 9, 200, 7, 60, 3}, 11);
+    for (auto &m : models) {
+      std::vector<double *> ptr;
+      for (auto &v : m.f) ptr.push_back(v.data());
+      CHECK(cals_hip_enqueue(e, m.rank, ptr.data(), m.lam.data(), -1, 0, &m.ticket) == CALS_HIP_OK);
+    }
+    cals_hip_report rep;
+    CHECK(cals_hip_run(e, &rep) == CALS_HIP_OK);
+    for (auto &m : models) CHECK(m.f == m.f0);
+    CHECK(cals_hip_destroy(e) == CALS_HIP_OK);
+  }
+}
+
 static void cpp_layer_driver_pattern() {
   using namespace cals;
   std::vector<dim_t> modes = {30, 25, 20};
@@ -245,6 +271,7 @@ int main() {
   c_abi_life_cycles(CALS_HIP_F64);
   c_abi_life_cycles(CALS_HIP_F32);
   stepwise_api();
+  n_way_group_tree();
   cpp_layer_driver_pattern();
   std::printf(failures ? "engine host asan: %d FAILED\n" : "engine host asan: all checks passed\n", failures);
   return failures ? 1 : 0;
