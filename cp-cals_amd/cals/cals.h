@@ -67,7 +67,7 @@ struct CalsReport {
   Matrix mttkrp_times{};
   vector<uint64_t> flops_per_iteration{};  // MFMA-kernel flops of the iteration: 2 * prod(modes) * cols per launch
   vector<dim_t> cols{};                    // active columns of the multi-factors per iteration
-  int mttkrp_plan{0};                      // added: cals_hip_tree of the engine that ran (0 / A / B / M)
+  int mttkrp_plan{0};                      // added: cals_hip_tree of the engine that ran (0 / A / B / M; 4 = N > 3 group tree)
 
   void print_header(const std::string &file_name, const std::string &sep = ";") const;
   void print_to_file(const std::string &file_name, const std::string &sep = ";") const;

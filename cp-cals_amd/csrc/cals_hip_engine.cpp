@@ -473,16 +473,15 @@ Geo geometry(const cals_hip_engine *e, const ModeLayout &L, int64_t R) {
   Geo g;
   g.NB = (int)((R + CALS_BN - 1) / CALS_BN);
   const long long U = (long long)(L.Ap / 16) * L.S;
-  long long T = e->n_cu / std::max(1, g.NB * L.m_blocks);
-  if (T < 1) T = 1;
-  if (T > U) T = U;
-  if ((long long)g.NB * L.m_blocks > e->n_cu / 2) {
-    // many column blocks: several rounds of finer workgroups (see pick_team); unit = 16 rows of the
-    // inner mode for one s, overhead ~ 1 % of a column block's units
-    const size_t nb_max = (size_t)((e->buffer + CALS_BN - 1) / CALS_BN);
-    T = pick_team((long long)g.NB * L.m_blocks, U, std::max<long long>(1, U / 100), e->n_cu,
-                  (long long)(partial_tile_cap(e, nb_max) / ((size_t)g.NB * L.m_blocks)));
-  }
+  // rounds x (units per member + overhead) over all team sizes (pick_team): one round while NB * m_blocks divides
+  // the chip well (C3: 21 x 12 = 252 workgroups), several rounds of finer workgroups otherwise -- many column
+  // blocks, or the 100 (column block, M block) pairs of a merged-mode view (80^4: T = 2 would leave 56 CUs idle,
+  // T = 5 runs two nearly full rounds).  unit = 16 rows of the inner mode for one s, overhead ~ 1 % of a column
+  // block's units
+  const size_t nb_max = (size_t)((e->buffer + CALS_BN - 1) / CALS_BN);
+  const long long T =
+      pick_team((long long)g.NB * L.m_blocks, U, std::max<long long>(1, U / 100), e->n_cu,
+                std::max<long long>(1, (long long)(partial_tile_cap(e, nb_max) / ((size_t)g.NB * L.m_blocks))));
   g.T = (int)T;
   return g;
 }
