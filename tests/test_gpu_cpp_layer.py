@@ -29,6 +29,17 @@ def test_reference_style_caller_runs(tmp_path):
     assert [int(ln.split(";")[8]) for ln in lines[1:]] == list(range(1, len(lines)))   # ITER column
 
 
+@pytest.mark.parametrize("modes", ["9-8-7-6", "6-5-4-5-3"])
+def test_reference_style_caller_on_n_way_tensors(modes):
+    """the same caller on 4- and 5-way tensors: the C++ layer over the two-group dimension tree (cp_cals == cp_als
+    per model, jackknife replicas in one call, the timer matrices with one MODE_n block per mode)"""
+    exe = os.path.join(ROOT, "tests", "cpp", "ref_style_caller")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    r = subprocess.run([exe, modes, "1:3:2"], capture_output=True, text=True, timeout=600)
+    print(r.stdout[-3000:], r.stderr[-3000:])
+    assert r.returncode == 0 and "all checks passed" in r.stdout, r.stderr[-2000:]
+
+
 def test_static_tensor_with_device_mirror_exits_cleanly():
     """The mirror's engine is destroyed during static destruction, after the HIP runtime's exit handlers:
     cals_hip_destroy must then leave HIP alone (drain_devices_at_exit sets the flag)."""
