@@ -1481,56 +1481,72 @@ __global__ void __launch_bounds__(256) group_contract_kernel(const GroupContract
   const int c = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const T *Tc = static_cast<const T *>(a.T) + a.ldT * c;
+  // the group padded to four modes with size-1 modes whose "factor" is the constant 1: plain nested loops, no
+  // index decoding (a 64-bit div / mod per element made the first version of this kernel 20x slower)
+  int d[4];
   const T *F[4];
-  for (int k = 0; k < a.h; ++k) F[k] = static_cast<const T *>(a.F[k]) + (long long)a.dims[k] * c;
+  for (int k = 0; k < 4; ++k) {
+    d[k] = k < a.h ? a.dims[k] : 1;
+    F[k] = k < a.h ? static_cast<const T *>(a.F[k]) + (long long)a.dims[k] * c : nullptr;
+  }
+  auto f = [&](int k, int i) { return F[k] ? (double)F[k][i] : 1.0; };
   T *out = static_cast<T *>(a.out) + (long long)a.dims[a.n_local] * c;
-  const int d0 = a.dims[0];
-  long long rest_total = 1;  // combinations of the indices 1 .. h-1
-  for (int k = 1; k < a.h; ++k) rest_total *= a.dims[k];
+  __shared__ double s_part[256];
   if (a.n_local == 0) {
-    for (int i0 = tid; i0 < d0; i0 += 256) {
+    // thread (tx, ty): tx = i_0 within a power-of-two stripe, ty = a contiguous share of the outermost other index
+    int stripe = 1;
+    while (stripe < d[0] && stripe < 256) stripe <<= 1;
+    const int parts = 256 / stripe, tx = tid % stripe, ty = tid / stripe;
+    // the outermost mode with more than one entry carries the split
+    const int ko = d[3] > 1 ? 3 : (d[2] > 1 ? 2 : 1);
+    const int lo = (int)((long long)d[ko] * ty / parts), hi = (int)((long long)d[ko] * (ty + 1) / parts);
+    for (int i0 = tx; i0 < d[0] || i0 - tx < d[0]; i0 += stripe) {  // uniform trip count over the stripe
       double acc = 0.0;
-      for (long long rest = 0; rest < rest_total; ++rest) {
-        long long q = rest;
-        double w = 1.0;
-        for (int k = 1; k < a.h; ++k) {
-          w *= (double)F[k][q % a.dims[k]];
-          q /= a.dims[k];
+      if (i0 < d[0]) {
+        for (int i3 = (ko == 3 ? lo : 0); i3 < (ko == 3 ? hi : d[3]); ++i3) {
+          const double w3 = f(3, i3);
+          for (int i2 = (ko == 2 ? lo : 0); i2 < (ko == 2 ? hi : d[2]); ++i2) {
+            const double w23 = w3 * f(2, i2);
+            const T *row = Tc + i0 + (long long)d[0] * d[1] * (i2 + (long long)d[2] * i3);
+            for (int i1 = (ko == 1 ? lo : 0); i1 < (ko == 1 ? hi : d[1]); ++i1)
+              acc += (double)row[(long long)d[0] * i1] * (w23 * f(1, i1));
+          }
         }
-        acc += (double)Tc[i0 + (long long)d0 * rest] * w;
       }
-      out[i0] = (T)acc;
+      s_part[tid] = acc;
+      __syncthreads();
+      if (ty == 0 && i0 < d[0]) {
+        double tot = 0.0;
+        for (int p = 0; p < parts; ++p) tot += s_part[tx + stripe * p];  // fixed order
+        out[i0] = (T)tot;
+      }
+      __syncthreads();
     }
     return;
   }
-  const int n = a.n_local, dn = a.dims[n];
-  long long below = 1, above = 1;  // products of the dims between 0 and n, and above n
-  for (int k = 1; k < n; ++k) below *= a.dims[k];
-  for (int k = n + 1; k < a.h; ++k) above *= a.dims[k];
-  for (int in = wave; in < dn; in += 4) {
+  // n_local > 0: the modes are renamed so that the result's mode is "n" and the two others (besides mode 0)
+  // are u and v; one wave per i_n at a time, lanes over i_0, wave butterfly at the end
+  const int n = a.n_local;
+  int u = -1, v = -1;
+  for (int k = 1; k < 4; ++k) {
+    if (k == n) continue;
+    if (u < 0)
+      u = k;
+    else
+      v = k;
+  }
+  long long str[4];
+  str[0] = 1;
+  for (int k = 1; k < 4; ++k) str[k] = str[k - 1] * d[k - 1];
+  for (int in = wave; in < d[n]; in += 4) {
     double acc = 0.0;
-    for (long long hi = 0; hi < above; ++hi) {
-      double whi = 1.0;
-      {
-        long long q = hi;
-        for (int k = n + 1; k < a.h; ++k) {
-          whi *= (double)F[k][q % a.dims[k]];
-          q /= a.dims[k];
-        }
-      }
-      for (long long lo = 0; lo < below; ++lo) {
-        double w = whi;
-        {
-          long long q = lo;
-          for (int k = 1; k < n; ++k) {
-            w *= (double)F[k][q % a.dims[k]];
-            q /= a.dims[k];
-          }
-        }
-        const long long rest = lo + below * (in + (long long)dn * hi);
-        const T *row = Tc + (long long)d0 * rest;
+    for (int iv = 0; iv < d[v]; ++iv) {
+      const double wv = f(v, iv);
+      for (int iu = 0; iu < d[u]; ++iu) {
+        const double w = wv * f(u, iu);
+        const T *row = Tc + str[n] * in + str[u] * iu + str[v] * iv;
         double part = 0.0;
-        for (int i0 = lane; i0 < d0; i0 += 64) part += (double)row[i0] * (double)F[0][i0];
+        for (int i0 = lane; i0 < d[0]; i0 += 64) part += (double)row[i0] * (double)F[0][i0];
         acc += part * w;
       }
     }
