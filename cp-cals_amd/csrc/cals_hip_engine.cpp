@@ -878,10 +878,6 @@ int sweep_once(cals_hip_engine *e, bool evict_enabled, bool defer_changed = fals
     u.factor = e->factor[n];
     u.dtype = e->dtype;
     u.I = (int)e->modes[n];
-    u.partial = e->partial;
-    u.NB = g.NB;
-    u.T = g.T;
-    u.ldPart = e->lay[n].ldPart;
     for (int m = 0; m < e->n_modes; m++) u.gram[m] = e->gram[m];
     u.lambda = e->lambda;
     u.n_modes = e->n_modes;

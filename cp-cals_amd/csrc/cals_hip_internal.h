@@ -141,8 +141,6 @@ struct UpdateArgs {
   void *factor;        // multi-factor of this mode (element type = dtype), I x buffer, ld = I
   int dtype;
   int I;
-  const void *partial;  // MTTKRP partial tiles (dtype)
-  int NB, T, ldPart;
   double *gram[CALS_MAX_MODES];  // column-indexed Gramian stores: CALS_GLD x buffer, ld CALS_GLD
   double *hscratch;    // ranks > CALS_RMAX in flight: one CALS_GLD x CALS_GLD block (H / L) per such model,
   int *hcounter;       // handed out through this counter (zeroed before the launch)
