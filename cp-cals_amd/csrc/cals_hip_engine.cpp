@@ -848,6 +848,9 @@ int sweep_once(cals_hip_engine *e, bool evict_enabled, bool defer_changed = fals
     e->sweep_log.resize((size_t)(e->sweeps - e->log_base) + 1, cals_hip_sweep_record{});
     e->sweep_log.back() = rec;
   }
+  // without a line search nothing runs between the last mode's update and the end-of-sweep rule: the update
+  // launch applies it (UpdateArgs::fin) and finish_kernel is not launched
+  const bool fin_in_update = !e->prm.line_search && (!e->prm.always_evict_first || !evict_enabled);
   for (int n = 0; n < e->n_modes; n++) {
     e->cur_mode = n;
     Geo g{0, 0};
@@ -883,6 +886,13 @@ int sweep_once(cals_hip_engine *e, bool evict_enabled, bool defer_changed = fals
     u.n_modes = e->n_modes;
     u.mode = n;
     u.is_last = (n == e->n_modes - 1);
+    if (u.is_last && fin_in_update) {
+      u.fin.on = 1;
+      u.fin.max_iter = e->prm.max_iterations;
+      u.fin.tol = e->prm.tol;
+      u.fin.force_max_iter = e->prm.force_max_iter;
+      u.fin.evict_enabled = evict_enabled ? 1 : 0;
+    }
     u.X_norm = e->X_norm;
     u.jk_norms = e->d_jk_norms;
     u.dbg_trace = e->dbg_trace ? e->dbg_trace + 16 * 2048 - 64 : nullptr;  // last 64 entries of the trace
@@ -965,7 +975,7 @@ int sweep_once(cals_hip_engine *e, bool evict_enabled, bool defer_changed = fals
       note_ls_changes(e, changed);
     }
   }
-  if (!e->prm.always_evict_first || !evict_enabled) {
+  if ((!e->prm.always_evict_first || !evict_enabled) && !fin_in_update) {
     FinishArgs f{};
     f.slots = e->d_slots;
     f.n_slots = ns;

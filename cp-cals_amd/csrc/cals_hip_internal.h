@@ -142,6 +142,15 @@ struct UpdateArgs {
   int dtype;
   int I;
   double *gram[CALS_MAX_MODES];  // column-indexed Gramian stores: CALS_GLD x buffer, ld CALS_GLD
+  // end-of-sweep rule (finish_kernel's: eviction flag or iters++, cals.cpp:336-354) applied by the last mode's
+  // launch itself when nothing runs between the update and the rule (no line search): one launch less per sweep
+  struct {
+    int on;
+    long long max_iter;
+    double tol;
+    int force_max_iter;
+    int evict_enabled;
+  } fin;
   double *hscratch;    // ranks > CALS_RMAX in flight: one CALS_GLD x CALS_GLD block (H / L) per such model,
   int *hcounter;       // handed out through this counter (zeroed before the launch)
   double *lambda;      // per column

@@ -42,6 +42,22 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 #define UPD_STAMP_H(k) do { } while (0)
 #endif
 
+// finish_kernel's rule for one model (see UpdateArgs::fin)
+__device__ __forceinline__ void apply_finish_rule(const UpdateArgs &a, int slot) {
+  const long long it = a.mt.iters[slot];
+  bool evict = false;
+  if (a.fin.evict_enabled) {
+    if (!a.fin.force_max_iter)
+      evict = (fabs(a.mt.old_fit[slot] - a.mt.fit[slot]) < a.fin.tol) || (it >= a.fin.max_iter);
+    else
+      evict = it >= a.fin.max_iter;
+  }
+  if (evict)
+    a.mt.flags[slot] |= 4;
+  else
+    a.mt.iters[slot] = it + 1;
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
@@ -447,6 +463,7 @@ __device__ __attribute__((noinline)) void update_body(const UpdateArgs &a, int s
       const double of = a.mt.fit[slot];
       a.mt.old_fit[slot] = of;
       a.mt.fit[slot] = 1.0 - fabs(err) / a.X_norm;
+      if (a.fin.on) apply_finish_rule(a, slot);
     }
   }
 }
@@ -764,6 +781,7 @@ __device__ __attribute__((noinline)) void update_body_lds(const UpdateArgs &a, i
       const double of = a.mt.fit[slot];
       a.mt.old_fit[slot] = of;
       a.mt.fit[slot] = 1.0 - fabs(err) / a.X_norm;
+      if (a.fin.on) apply_finish_rule(a, slot);
     }
   }
 }
@@ -1247,6 +1265,7 @@ __device__ __attribute__((noinline)) void update_body_huge(const UpdateArgs &a, 
       const double of = a.mt.fit[slot];
       a.mt.old_fit[slot] = of;
       a.mt.fit[slot] = 1.0 - fabs(err) / a.X_norm;
+      if (a.fin.on) apply_finish_rule(a, slot);
     }
   }
 }

@@ -109,7 +109,21 @@ hipError_t contract_launch(const void *, long long, int, int, const void *, long
 }
 hipError_t krp_launch(const KrpArgs &, hipStream_t) { return hipSuccess; }
 hipError_t group_contract_launch(const GroupContractArgs &, hipStream_t) { return hipSuccess; }
-hipError_t update_launch(const UpdateArgs &, int, hipStream_t) { return hipSuccess; }
+hipError_t finish_launch(const FinishArgs &a, hipStream_t);
+// the numeric part is a no-op; the end-of-sweep rule the real launch applies for the last mode (UpdateArgs::fin)
+// is the fake finish rule below
+hipError_t update_launch(const UpdateArgs &a, int, hipStream_t st) {
+  if (!a.fin.on) return hipSuccess;
+  FinishArgs f{};
+  f.slots = a.slots;
+  f.n_slots = a.n_slots;
+  f.mt = a.mt;
+  f.max_iter = a.fin.max_iter;
+  f.tol = a.fin.tol;
+  f.force_max_iter = a.fin.force_max_iter;
+  f.evict_enabled = a.fin.evict_enabled;
+  return finish_launch(f, st);
+}
 hipError_t nnls_launch(const NnlsArgs &, hipStream_t) { return hipSuccess; }
 int nnls_rank_class(int r) { return r <= 24 ? 0 : r <= 32 ? 1 : r <= 48 ? 2 : r <= CALS_RMAX ? 3 : 4; }
 size_t nnls_huge_block_doubles() { return (size_t)CALS_GLD * CALS_GLD * 9; }
