@@ -152,3 +152,47 @@ def test_a_bigger_4_way_tensor_tree_equals_plain(cc, inputs):
         for fa, fb in zip(a.factors, b.factors):
             assert rel(fa, fb) < 1e-9
         assert abs(a.error - b.error) <= 1e-9 * max(1.0, b.error)
+
+
+def _random_nway_cases(n, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n):
+        nm = int(rng.integers(4, 8))
+        cap = {4: 14, 5: 8, 6: 6, 7: 4}[nm]
+        modes = [int(v) for v in rng.integers(1 if rng.integers(0, 6) == 0 else 2, cap + 1, size=nm)]
+        n_models = int(rng.integers(2, 8))
+        pr = sorted(modes)
+        # keep the Hadamard of the N - 1 Gramians well conditioned (a failed dpotrf leaves nothing to compare):
+        # rank well below the product of the three smallest modes
+        rmax = max(1, min(24, (pr[0] * pr[1] * pr[2]) // 4))
+        ranks = [int(v) for v in rng.integers(1, rmax + 1, size=n_models)]
+        buffer = int(rng.integers(max(ranks), max(max(ranks) + 1, sum(ranks))))
+        out.append((modes, ranks, buffer, int(rng.integers(0, 3)), int(rng.integers(0, 1 << 30))))
+    return out
+
+
+_N_NWAY = int(os.environ.get("CALS_SOAK_NWAY", "16"))
+
+
+@pytest.mark.parametrize("modes,ranks,buffer,flavour,seed",
+                         _random_nway_cases(_N_NWAY, 31337 + int(os.environ.get("CALS_SOAK_SEED", "0"))))
+def test_random_n_way_queue_life_cycles(cc, oracle, inputs, modes, ranks, buffer, flavour, seed):
+    """random 4- to 7-way shapes (size-1 modes included), a queue longer than the buffer, tolerance-driven eviction,
+    flavour 0 plain / 1 line search / 2 NNLS: the same admission order, sweep counts and fitted tensors as the
+    oracle."""
+    X = inputs.tensor(modes, seed % 1000)
+    kw = dict(tol=1e-3, force_max_iter=0)
+    if flavour == 1:
+        kw.update(line_search=1, line_search_interval=3)
+    elif flavour == 2:
+        kw["update_method"] = 1
+        X = np.abs(X)
+    with plan(None):
+        gm, om, rep, ro = _run_both(cc, oracle, inputs, modes, ranks, X, 15, buffer=buffer, **kw)
+    assert (rep.iter, rep.n_ktensors, rep.ktensor_comp_sum) == (ro.iter, ro.n_ktensors, ro.ktensor_comp_sum)
+    assert (rep.ls_performed, rep.ls_failed) == (ro.ls_performed, ro.ls_failed)
+    for a, b in zip(gm, om):
+        assert a.iters == b.iters
+        d = np.linalg.norm(reconstruct(a.factors, a.lam, modes) - reconstruct(b.factors, b.lam, modes))
+        assert d <= 1e-7 * max(1.0, np.linalg.norm(X))

@@ -71,10 +71,21 @@ def test_random_shape_mttkrp_and_sweeps(cc, oracle, inputs, modes, ranks, plan, 
             max_iterations=4, force_max_iter=1, line_search=seed & 1, line_search_interval=2,
             mttkrp_method=oracle.MTTKRP, buffer_size=sum(ranks)))
         rtol = 1e-8 if dtype == "f64" else 2e-3
+        from helpers import reconstruct
+        xn = np.linalg.norm(X)
         for a, b in zip(gm, om):
             assert a.iters == b.iters
-            for fa, fb in zip(a.factors, b.factors):
-                assert rel(fa, fb) < rtol
+            if dtype == "f64":
+                for fa, fb in zip(a.factors, b.factors):
+                    assert rel(fa, fb) < rtol
+            else:
+                # fp32 storage: the fitted tensor, not the raw factors.  From a model's second sweep on a column is
+                # scaled by its entry of largest magnitude WITH ITS SIGN (Ktensor::normalize, ktensor.cpp:72-80); two
+                # entries of opposite sign whose magnitudes agree to fp32 rounding make that choice -- and with it the
+                # sign of the column and of lambda -- a coin toss between fp32 and fp64 runs (seen once in 500 soak
+                # cases); the product of the factors is unaffected.
+                d = np.linalg.norm(reconstruct(a.factors, a.lam, modes) - reconstruct(b.factors, b.lam, modes))
+                assert d <= rtol * xn
     finally:
         if old is None:
             os.environ.pop("CALS_HIP_TREE", None)
