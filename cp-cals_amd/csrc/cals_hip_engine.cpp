@@ -919,6 +919,7 @@ int sweep_once(cals_hip_engine *e, bool evict_enabled, bool defer_changed = fals
       q.status = e->d_nnls_status;
       q.rmax = rank_max;
       q.rank_classes = rank_classes;
+      q.dbg_counts = e->dbg_trace ? e->dbg_trace + 8 * 2048 + 1024 : nullptr;  // CALS_DIAG + CALS_TTM_TRACE: row / solve counters
       q.hscratch = e->nnls_hscratch;
       q.hcounter = e->d_hcounter;
       HIPCHK(nnls_launch(q, e->stream));

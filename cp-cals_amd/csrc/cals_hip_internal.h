@@ -185,6 +185,7 @@ struct NnlsArgs {
   unsigned rank_classes;  // bit k: a model of nnls_rank_class k is in flight (0: one launch sized by rmax)
   int rlo, rhi;        // set by nnls_launch: the ranks this launch serves
   int chunks;          // set by nnls_launch: workgroups per model
+  unsigned long long *dbg_counts;  // CALS_DIAG builds: {rows, solves, factorisations, main-loop passes, inner passes}
   double *hscratch;    // models above CALS_RMAX: n_huge * nnls_huge_chunks(I) blocks of nnls_huge_block_doubles()
   int *hcounter;       // zero at launch: blocks are handed out in arrival order
 };

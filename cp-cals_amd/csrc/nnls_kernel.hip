@@ -23,7 +23,9 @@
 //
 // Arithmetic: operation order of the Cholesky, the forward substitution and w = y - G d follows the
 // Netlib algorithms behind dposv/dgemv; the back substitution is column-oriented (the sums run
-// from the last passive entry down), i.e. equal to the reference up to rounding.  The NNLS
+// from the last passive entry down) and every division by a diagonal entry of the factor is a multiplication
+// by its reciprocal (one division per column of a factorisation, none in the substitutions), i.e. equal to the
+// reference up to rounding.  The NNLS
 // minimiser of a row is unique for an SPD H, so the active-set path may differ on exact ties without
 // changing the result beyond the tolerance the algorithm itself uses.
 #include "cals_hip_internal.h"
@@ -76,13 +78,22 @@ __device__ __forceinline__ unsigned long long uniform64(unsigned long long v) {
 }
 
 struct WaveScratch {
+  unsigned n_solves = 0, n_factor = 0;  // CALS_DIAG statistics
   unsigned long long cached;  // passive set whose factor is in Lw / dg (0: none)
-  double dg;                  // lane p: L[p][p] of that factor
+  double dg;                  // lane p: 1 / L[p][p] of that factor (the substitutions multiply: an IEEE f64
+                              // division is ~25 instructions, and this kernel is issue bound)
   double *Lw;   // strict lower triangle of the Cholesky factor of G[P,P], row p at Lw + p * ldw
   int ldw;
   int *idx;     // idx[p]: component of the p-th passive entry
   double *cv;   // compacted right-hand side
   double *xs;   // solution scattered back to component order
+  // the factor of the FULL set (every constraint passive), computed once per workgroup: a row of a model fitted to
+  // non-negative data starts all-passive in every sweep (y > 0 for every component), while its second solve -- about
+  // every other row drops a component -- used to evict that factor from the wave's one-entry cache, so the next row
+  // factored the full set again (tools/nnls_counts.py: 1.0 factorisations per row for 1.5 solves)
+  const double *Lf;   // strict lower triangle, row p at Lf + p * ldw
+  const double *dgf;  // dgf[p] = 1 / L[p][p]
+  unsigned long long fmask;  // the full set (0: not available)
 };
 
 // calculate_sp (update.cpp:18-48): x[i] = (G[P,P]^-1 y[P])[i] for i in P, 0 elsewhere.
@@ -106,17 +117,21 @@ __device__ bool solve_passive(const double *Hs, int r, WaveScratch &ws, unsigned
   double dg = 1.0;
   double *Lw = ws.Lw;
   const int ldw = ws.ldw;
-  if (pas == ws.cached) {
-    dg = ws.dg;
+  ws.n_solves++;
+  const bool full = ws.fmask && pas == ws.fmask;
+  const double *Ls = full ? ws.Lf : Lw;  // the factor the substitutions read
+  if (full || pas == ws.cached) {
+    dg = full ? ws.dgf[p] : ws.dg;
     for (int j = 0; j < np; ++j) {  // L z = b with the cached factor, same operation order
-      const double zj = bcast(t, j) / bcast(dg, j);
+      const double zj = bcast(t, j) * bcast(dg, j);
       if (p == j)
         t = zj;
       else if (valid && p > j)
-        t -= Lw[p * ldw + j] * zj;
+        t -= Ls[p * ldw + j] * zj;
     }
   } else {
   ws.cached = 0;
+  ws.n_factor++;
   for (int j = 0; j < np; ++j) {
     const int ij = __builtin_amdgcn_readfirstlane(ws.idx[j]);
     const bool below = valid && p > j;
@@ -126,6 +141,8 @@ __device__ bool solve_passive(const double *Hs, int r, WaveScratch &ws, unsigned
     const double *rj = Lw + j * ldw, *ri = Lw + lrow * ldw;
     int k = 0;
     for (; k + 4 <= j; k += 4) {  // four load pairs in flight; the subtractions stay in k order
+      // (row j could also come from lane j by v_readlane instead of a broadcast LDS load: measured slower,
+      // 1.25 vs 1.10 ms of update stage per sweep at C3's shape -- the kernel is issue bound, not LDS bound)
       const double l0 = rj[k], l1 = rj[k + 1], l2 = rj[k + 2], l3 = rj[k + 3];
       const double m0 = ri[k], m1 = ri[k + 1], m2 = ri[k + 2], m3 = ri[k + 3];
       ajj -= l0 * l0;
@@ -144,13 +161,13 @@ __device__ bool solve_passive(const double *Hs, int r, WaveScratch &ws, unsigned
     }
     ajj = first_lane(ajj);
     if (!(ajj > 0.0)) return false;
-    const double ljj = sqrt(ajj);
-    const double lij = sv / ljj;
+    const double rl = 1.0 / sqrt(ajj);  // the one division of the column
+    const double lij = sv * rl;
     if (below) Lw[p * ldw + j] = lij;
-    const double zj = bcast(t, j) / ljj;  // forward substitution, column by column
+    const double zj = bcast(t, j) * rl;  // forward substitution, column by column
     if (p == j) {
       t = zj;
-      dg = ljj;
+      dg = rl;
     } else if (below) {
       t -= lij * zj;
     }
@@ -160,11 +177,11 @@ __device__ bool solve_passive(const double *Hs, int r, WaveScratch &ws, unsigned
   ws.dg = dg;
   }
   for (int j = np - 1; j >= 0; --j) {  // L^T x = z
-    const double xj = bcast(t, j) / bcast(dg, j);
+    const double xj = bcast(t, j) * bcast(dg, j);
     if (p == j)
       t = xj;
     else if (valid && p < j)
-      t -= Lw[j * ldw + p] * xj;
+      t -= Ls[j * ldw + p] * xj;
   }
   if (valid) ws.xs[myi] = t;
   WAVE_SYNC();
@@ -202,7 +219,11 @@ __global__ void __launch_bounds__(256) nnls_kernel(const NnlsArgs a) {
   {
     const int ldw = r | 1;
     const size_t per_wave = (size_t)a.rmax * (a.rmax | 1) + 64 + 64 + 32;  // doubles (idx: 64 ints)
-    double *base = Hs + (size_t)a.rmax * a.rmax + per_wave * wave;
+    double *shared_f = Hs + (size_t)a.rmax * a.rmax;  // the workgroup's full-set factor + its diagonal
+    double *base = shared_f + (size_t)a.rmax * (a.rmax | 1) + 64 + per_wave * wave;
+    ws.Lf = shared_f;
+    ws.dgf = shared_f + (size_t)a.rmax * (a.rmax | 1);
+    ws.fmask = 0;
     ws.Lw = base;
     ws.ldw = ldw;
     ws.cv = base + (size_t)a.rmax * (a.rmax | 1);
@@ -229,14 +250,29 @@ __global__ void __launch_bounds__(256) nnls_kernel(const NnlsArgs a) {
     tol = 10 * 2.2204e-16 * wave_max(cs) * (double)r;
   }
   const unsigned long long rmask = (r >= 64) ? ~0ull : ((1ull << r) - 1ull);
+  {  // wave 0 factors the full set into the shared tile (same routine, a zero right-hand side)
+    __shared__ int s_full_ok;
+    if (wave == 0) {
+      WaveScratch wf = ws;
+      wf.Lw = const_cast<double *>(ws.Lf);
+      double unused;
+      const bool ok = solve_passive(Hs, r, wf, rmask, r, 0.0, lane, unused);
+      if (ok) const_cast<double *>(ws.dgf)[lane] = wf.dg;
+      if (lane == 0) s_full_ok = ok ? 1 : 0;
+    }
+    __syncthreads();
+    if (s_full_ok) ws.fmask = rmask;
+  }
   T *fac = static_cast<T *>(a.factor) + (long long)I * col;
   unsigned long long *actp = a.act + (long long)I * col;
   double *rowdot = a.rowdot + (long long)I * k_model;
   const int rows_per = (I + a.chunks - 1) / a.chunks;
   const int row0 = chunk * rows_per, row1 = min(I, row0 + rows_per);
   int status = 0;
+  unsigned n_rows = 0, n_main = 0, n_inner = 0, n_full = 0;  // CALS_DIAG statistics
 
   for (int row = row0 + wave; row < row1; row += W) {
+    n_rows++;
     const bool in = lane < r;
     const double y = in ? (double)fac[row + (long long)I * lane] : 0.0;
     unsigned long long act = uniform64(actp[row]) & rmask;
@@ -244,6 +280,7 @@ __global__ void __launch_bounds__(256) nnls_kernel(const NnlsArgs a) {
     double d = 0.0, sp = 0.0;
     int budget = NNLS_MAX_EXCHANGES;
     unsigned long long pas = ~act & rmask;
+    if (pas == rmask) n_full++;
     if (pas) {  // warm start (update.cpp:93-121)
       bool failed = !solve_passive(Hs, r, ws, pas, __popcll(pas), y, lane, sp);
       if (!failed) {
@@ -281,6 +318,7 @@ __global__ void __launch_bounds__(256) nnls_kernel(const NnlsArgs a) {
       const bool ia = (act >> lane) & 1ull;
       const double wmax = wave_max(ia ? w : -DBL_MAX);
       if (!(wmax > tol)) break;
+      n_main++;
       const unsigned long long hit = __ballot(ia && w == wmax);
       const int m = __ffsll((long long)hit) - 1;  // Tensor::max_id: the first of equal maxima
       act &= ~(1ull << m);
@@ -293,6 +331,7 @@ __global__ void __launch_bounds__(256) nnls_kernel(const NnlsArgs a) {
       for (;;) {  // inner loop (update.cpp:136-157)
         const bool ip = (pas >> lane) & 1ull;
         if (!(wave_min(ip ? sp : DBL_MAX) <= tol)) break;
+        n_inner++;
         const double alpha = wave_min((ip && sp <= tol) ? d / (d - sp) : DBL_MAX);
         if (in) d = d + alpha * (sp - d);
         const bool na = ip && fabs(d) < tol;
@@ -330,6 +369,20 @@ __global__ void __launch_bounds__(256) nnls_kernel(const NnlsArgs a) {
     }
   }
   if (status && lane == 0) atomicOr(a.status, status);
+  (void)n_rows;
+  (void)n_main;
+  (void)n_inner;
+  (void)n_full;
+#ifdef CALS_DIAG
+  if (a.dbg_counts && lane == 0) {
+    atomicAdd(a.dbg_counts + 0, (unsigned long long)n_rows);
+    atomicAdd(a.dbg_counts + 1, (unsigned long long)ws.n_solves);
+    atomicAdd(a.dbg_counts + 2, (unsigned long long)ws.n_factor);
+    atomicAdd(a.dbg_counts + 3, (unsigned long long)n_main);
+    atomicAdd(a.dbg_counts + 4, (unsigned long long)n_inner);
+    atomicAdd(a.dbg_counts + 5, (unsigned long long)n_full);
+  }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -756,7 +809,7 @@ int nnls_rank_class(int r) { return r <= 24 ? 0 : r <= 32 ? 1 : r <= 48 ? 2 : r 
 
 size_t nnls_lds_bytes(int rmax, int waves) {
   const size_t per_wave = (size_t)rmax * (rmax | 1) + 64 + 64 + 32;
-  return ((size_t)rmax * rmax + per_wave * waves) * sizeof(double);
+  return ((size_t)rmax * rmax + (size_t)rmax * (rmax | 1) + 64 + per_wave * waves) * sizeof(double);
 }
 
 hipError_t nnls_launch(const NnlsArgs &a_in, hipStream_t st) {
