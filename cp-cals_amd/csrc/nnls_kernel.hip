@@ -161,7 +161,11 @@ __device__ bool solve_passive(const double *Hs, int r, WaveScratch &ws, unsigned
     }
     ajj = first_lane(ajj);
     if (!(ajj > 0.0)) return false;
-    const double rl = 1.0 / sqrt(ajj);  // the one division of the column
+    // 1 / sqrt(a_jj): v_rsq_f64 + two Newton steps (as update_kernel's register Cholesky; an IEEE sqrt followed by
+    // an IEEE divide is ~55 instructions per column).  Entries differ from sqrt / divide by an ulp or two.
+    double rl = __builtin_amdgcn_rsq(ajj);
+    rl = rl * fma(-0.5 * ajj * rl, rl, 1.5);
+    rl = rl * fma(-0.5 * ajj * rl, rl, 1.5);
     const double lij = sv * rl;
     if (below) Lw[p * ldw + j] = lij;
     const double zj = bcast(t, j) * rl;  // forward substitution, column by column
