@@ -32,6 +32,7 @@
 
 #include <algorithm>
 #include <cfloat>
+#include <cstdlib>
 
 namespace calship {
 
@@ -851,6 +852,8 @@ hipError_t nnls_launch(const NnlsArgs &a_in, hipStream_t st) {
     const size_t dyn = nnls_lds_bytes(a.rmax, waves);
     // rows per workgroup: at least 4 per wave, enough workgroups to fill 256 CUs several times over
     a.chunks = std::max(1, std::min((a.I + 4 * waves - 1) / (4 * waves), (4096 + a.n_slots - 1) / a.n_slots));
+    static const int forced_chunks = getenv("CALS_NNLS_CHUNKS") ? atoi(getenv("CALS_NNLS_CHUNKS")) : 0;  // experiments
+    if (forced_chunks > 0) a.chunks = std::min(forced_chunks, a.I);
     const dim3 grid((unsigned)(a.n_slots * a.chunks)), block(64 * waves);
     if (di)
       hipLaunchKernelGGL(nnls_kernel<float>, grid, block, dyn, st, a);
