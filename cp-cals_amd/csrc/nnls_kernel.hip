@@ -36,7 +36,11 @@
 
 namespace calship {
 
-#define NNLS_MAX_EXCHANGES 4096  // set exchanges per row; the reference's loops are unbounded (status bit 2)
+// set exchanges per row: the reference's loops are unbounded and its exchange rule cycles on some inputs (it
+// would not return); max(64, 16 r) is far above what a terminating row needs, and a cycling row no longer holds
+// the launch for 4096 solves (an all-positive noise tensor at C3's shape: 3 such rows per launch were 1.0 of
+// the kernel's 1.35 ms).  Reported as status bit 2.  Same rule as the oracle's OR_NNLS_MAX_EXCHANGES.
+#define NNLS_MAX_EXCHANGES(r) ((r) > 4 ? 16 * (r) : 64)
 
 #define WAVE_SYNC()                                           \
   do {                                                        \
@@ -283,7 +287,7 @@ __global__ void __launch_bounds__(256) nnls_kernel(const NnlsArgs a) {
     unsigned long long act = uniform64(actp[row]) & rmask;
     act &= ~__ballot(in && y > 0.0);  // "determine previous active set" (update.cpp:87-91)
     double d = 0.0, sp = 0.0;
-    int budget = NNLS_MAX_EXCHANGES;
+    int budget = NNLS_MAX_EXCHANGES(r);
     unsigned long long pas = ~act & rmask;
     if (pas == rmask) n_full++;
     if (pas) {  // warm start (update.cpp:93-121)
@@ -694,7 +698,7 @@ __global__ void __launch_bounds__(64 * NNLS_HWAVES) nnls_huge_kernel(const NnlsA
       act[q] &= ~__ballot(in[q] && y[q] > 0.0);  // "determine previous active set"
       pas[q] = ~act[q] & rmask[q];
     }
-    int budget = NNLS_MAX_EXCHANGES;
+    int budget = NNLS_MAX_EXCHANGES(r);
     // min over the passive entries of sp / over the given per-lane values
     auto min_passive_sp = [&]() {
       double v = DBL_MAX;

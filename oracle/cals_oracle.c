@@ -441,9 +441,12 @@ static int nnls_any(const uint8_t *active, int64_t n, int value) {
 }
 
 /* The reference's loops have no iteration bound (an active-set method ends after finitely many
- * exchanges in exact arithmetic).  The restatement stops a row after OR_NNLS_MAX_EXCHANGES passes
- * of either loop and reports it, so that a cycling row cannot hang a test. */
-#define OR_NNLS_MAX_EXCHANGES 4096
+ * exchanges in exact arithmetic -- in floating point the exchange rule does cycle on some inputs, e.g. rank-48 models
+ * on an all-positive noise tensor: the reference would not return).  The restatement stops a row after
+ * OR_NNLS_MAX_EXCHANGES(n) = max(64, 16 n) passes of either loop and reports it (status 2): far above what a
+ * terminating row needs (Lawson-Hanson implementations commonly allow 3 n), so that a cycling row cannot hang a
+ * test or, on the device, hold a whole launch for thousands of solves. */
+#define OR_NNLS_MAX_EXCHANGES (n > 4 ? 16 * n : 64)
 
 /* panel: rows x r (ld) holding the MTTKRP result, overwritten with the constrained solution;
  * H: r x r (ld r) Hadamard product of the other Gramians (NOT destroyed, unlike the unconstrained
