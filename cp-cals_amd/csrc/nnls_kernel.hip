@@ -330,6 +330,7 @@ __global__ void __launch_bounds__(256) nnls_kernel(const NnlsArgs a) {
       n_main++;
       const unsigned long long hit = __ballot(ia && w == wmax);
       const int m = __ffsll((long long)hit) - 1;  // Tensor::max_id: the first of equal maxima
+      const unsigned long long act_top = act;  // the set this pass starts from (cycle test below)
       act &= ~(1ull << m);
       pas = ~act & rmask;
       if (!solve_passive(Hs, r, ws, pas, __popcll(pas), y, lane, sp)) {
@@ -365,6 +366,13 @@ __global__ void __launch_bounds__(256) nnls_kernel(const NnlsArgs a) {
       if (stop) break;
       d = sp;
       w = multipliers(Hs, r, y, d, lane);
+      // a pass that ends on the set it started from has reproduced its own starting state (d and w are
+      // functions of the set): every further pass repeats it -- the reference's loop never ends here.  Stop at
+      // the first such pass, report it like the bound (same rule in the oracle).
+      if (act == act_top) {
+        status |= 2;
+        break;
+      }
       if (--budget <= 0) {
         status |= 2;
         break;
@@ -746,6 +754,8 @@ __global__ void __launch_bounds__(64 * NNLS_HWAVES) nnls_huge_kernel(const NnlsA
       HQ_FOR if ((act[q] >> lane) & 1ull) wl = fmax(wl, w[q]);
       const double wmax = wave_max(wl);
       if (!(wmax > tol)) break;
+      u64 act_top[NNLS_HQ];  // the set this pass starts from (cycle test below)
+      HQ_FOR act_top[q] = act[q];
       {  // Tensor::max_id: the first of equal maxima = lowest component = lowest word, then lowest lane
         bool taken = false;
         HQ_FOR {
@@ -792,6 +802,14 @@ __global__ void __launch_bounds__(64 * NNLS_HWAVES) nnls_huge_kernel(const NnlsA
       if (stop) break;
       HQ_FOR d[q] = sp[q];
       multipliers_huge(Hs, r, ws, y, d, lane, w);
+      {  // the pass ended on the set it started from: a cycle of the exchange rule (see nnls_kernel)
+        bool same = true;
+        HQ_FOR same = same && act[q] == act_top[q];
+        if (same) {
+          status |= 2;
+          break;
+        }
+      }
       if (--budget <= 0) {
         status |= 2;
         break;

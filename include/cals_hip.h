@@ -66,7 +66,7 @@ typedef struct {
   double loop_ms;           /* do{}while loop only (host clock, device synchronised) */
   int nnls_status;          /* NNLS update, OR over all rows since create: 0 clean; 1 a Cholesky failed in
                              * the main loop (the reference ends on the uncaught CholFail, update.cpp:131);
-                             * 2 a row hit the bound of max(64, 16 rank) set exchanges (the reference has none) */
+                             * 2 a row cycled or hit the bound of max(64, 16 rank) set exchanges (the reference has neither test) */
 } cals_hip_report;
 
 /* Per-model results that the reference keeps inside Ktensor (include/ktensor.h:27-33). */

@@ -466,6 +466,7 @@ int or_update_factor_nnls(double *panel, int64_t rows, int64_t r, int64_t ld, co
   const double tol = 10 * eps * one_norm * (double)n;
   double *y = (double *)xmalloc(sizeof(double) * (size_t)(6 * n + n * n));
   double *d = y + n, *w = d + n, *s = w + n, *sp = s + n, *Gp = sp + n;
+  uint8_t *top = (uint8_t *)xmalloc((size_t)n);
   int status = 0;
   for (int64_t i = 0; i < n; i++) sp[i] = 0.0;
   for (int64_t row = 0; row < rows; row++) {
@@ -503,6 +504,7 @@ int or_update_factor_nnls(double *panel, int64_t rows, int64_t r, int64_t ld, co
     int64_t guard = 0;
     while (nnls_any(active, n, 1) && w[nnls_max_id(w, active, n)] > tol) { /* main loop, :126-167 */
       const int64_t m = nnls_max_id(w, active, n);
+      memcpy(top, active, (size_t)n); /* the set this pass starts from (cycle test below) */
       active[m] = 0;
       int64_t np = nnls_calculate_sp(y, sp, H, Gp, active, n);
       if (np < 0) { status |= 1; break; }
@@ -529,10 +531,16 @@ int or_update_factor_nnls(double *panel, int64_t rows, int64_t r, int64_t ld, co
       if (np < 0) break;
       nnls_scatter(d, sp, active, n);
       nnls_multipliers(y, H, d, w, n);
+      /* A pass that ends on the set it started from (the variable it made passive left again in the inner
+       * loop) has reproduced its own starting state -- d and w are functions of the set -- so every further
+       * pass repeats it: this is where the reference's exchange rule cycles and its loop never ends.  Stop at the
+       * first such pass (same state as after any number of them) and report it like the bound. */
+      if (memcmp(top, active, (size_t)n) == 0) { status |= 2; break; }
       if (++guard > OR_NNLS_MAX_EXCHANGES) { status |= 2; break; }
     }
     for (int64_t i = 0; i < n; i++) panel[row + ld * i] = d[i];
   }
+  free(top);
   free(y);
   return status;
 }
