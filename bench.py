@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """bench.py -- the CALS hot path on N MI355X GPUs of one node.
 
-  python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: either launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`, or
+  started plainly -- WORLD_SIZE unset -- in which case this process, before any GPU call, starts exactly that
+  launcher as a child, relays rank 0's line and exits with the child's status)
 
 A step = one ALS sweep (every mode: MTTKRP + batched update; error; line search) of all models in
 flight on a GPU.  Workload (BASELINE.json config 3, the one north_star's target is quoted on):
@@ -11,7 +14,9 @@ cp-cals_amd/inputs.py.  X, factors and all model state are resident in HBM befor
 N > 1: weak scaling, every rank owns its own 256-model shard (model m -> GPU m mod N), X replicated,
 no data-path collective; value = sweeps completed by all ranks / max-over-ranks time.
 --workload c5 = BASELINE config 5: 2048 jackknife models IN TOTAL (jk = (mode 0, fiber m mod 300)),
-model m -> GPU m mod N, strong scaling (a step = one sweep of the whole job).
+model m -> GPU m mod N, strong scaling (a step = one sweep of the whole job).  The default (c3) run ALSO
+times that strong-scaling job right after the weak one and reports it under `strong_c5` (its own K steps,
+own barrier-bracketed region, per-rank ms/step): one command per N yields both of north_star's numbers.
 Rank 0 prints ONE JSON line: the contract fields, `roofline`, `cpu_baseline`, and beside them
 `steady_state` (>= 200 further sweeps), `run_loop` (the cals_hip_step loop users run: status
 read-back + eviction decision every sweep) and `dist` (backend, world size seen by the process
@@ -64,10 +69,13 @@ def cpu_baseline(modes, ranks, X, base, jk, ls, threads_all, protocol):
     timed after one warm-up sweep, best of `reps` repetitions of `sweeps` forced sweeps, best variant
     reported, for threads in {all of the cgroup's share, 1}.  protocol "bounded" (default: the bench
     has to finish within minutes) = 1 repetition of 3 sweeps at all threads, the best variant only
-    (1 sweep) at 1 thread; protocol "full" = 3 x 10 sweeps at all threads, 1 x 2 sweeps at 1 thread."""
+    (1 sweep) at 1 thread; protocol "middle" (default since round 3: about a minute) = best of 2 x 5 sweeps per
+    variant at all threads, the best variant 1 x 2 sweeps at 1 thread; protocol "full" = 3 x 10 sweeps at all
+    threads, every variant 1 x 2 sweeps at 1 thread."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle as O
-    plan = {"bounded": {"all": (1, 3), "one": (1, 1)}, "full": {"all": (3, 10), "one": (1, 2)}}[protocol]
+    plan = {"bounded": {"all": (1, 3), "one": (1, 1)}, "middle": {"all": (2, 5), "one": (1, 2)},
+            "full": {"all": (3, 10), "one": (1, 2)}}[protocol]
     have_mkl = O.use_mkl(threads_all)
     variants = (("MTTKRP", O.MTTKRP), ("TWOSTEP0", O.TWOSTEP0), ("TWOSTEP1", O.TWOSTEP1))
 
@@ -111,6 +119,72 @@ def cpu_baseline(modes, ranks, X, base, jk, ls, threads_all, protocol):
     }
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: this process has made no GPU call (torch is
+    not even imported yet), so it starts the launcher the contract names as a CHILD -- one rank per GPU, rendezvous on
+    127.0.0.1 at a free port -- with the same arguments, lets the children write to its stdout / stderr (rank 0
+    prints the JSON line) and exits with the launcher's status.  Never an exec: a process that may have touched the
+    GPU must not be replaced."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this pool (RCCL needs it)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def strong_c5_leg(cc, inputs, sharding, torch, X, world, rank, local_rank, steps, warmup, red_dev):
+    """BASELINE config 5 next to the weak line: 2048 jackknife models IN TOTAL on C3's X, model m -> GPU m mod N,
+    one step = one sweep of the whole job, job rate = K / max-over-ranks time of its own barrier-bracketed region.
+    N = 1 gives the denominator of north_star's ">= 6x at 8 GPUs"."""
+    modes, total, ls = WORKLOADS["c5"]
+    mine = sharding.shard_round_robin(total, world, rank)
+    ranks = [1 + (m % 20) for m in mine]
+    R = sum(ranks)
+    base = inputs.model_factors(modes, ranks, seed=101 + rank)
+    jk = [(0, m % modes[0]) for m in mine]
+    for (fs, _), (jm, jf) in zip(base, jk):
+        fs[jm][jf, :] *= 0.0
+    eng = cc.Engine(modes, R, device=local_rank, dtype="f64")
+    eng.set_tensor(X)
+    eng.set_params(cc.default_params(max_iterations=10 ** 9, force_max_iter=1, line_search=ls,
+                                     line_search_interval=5, line_search_step=0.0))
+    for k, (fs, lam) in enumerate(base):
+        eng.enqueue(cc.Model(fs, lam, jk=jk[k]))
+    assert eng.admit() == len(mine) and eng.active_cols == R
+    eng.set_profiling(3)
+    eng.sweep(warmup)
+    eng.synchronize()
+    eng.reset_kernel_stats()
+    sharding.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    eng.sweep(steps)
+    torch.cuda.synchronize()
+    sharding.barrier()
+    elapsed = time.perf_counter() - t0
+    value, t_max = sharding.strong_rate(steps, elapsed, device=red_dev)
+    per_rank_ms = [round(t / steps * 1e3, 4) for t in sharding.gather_over_ranks(elapsed, device=red_dev)]
+    ks = eng.kernel_stats()
+    eng.set_profiling(False)
+    eng.close()
+    out = {"metric": "ALS iterations/sec of the whole 2048-model job", "value": round(value, 3), "unit": "ALS it/s",
+           "scaling": "strong", "n_gpus": world, "steps": steps, "warmup": warmup,
+           "ms_per_step": round(t_max / steps * 1e3, 4), "ms_per_step_per_rank": per_rank_ms,
+           "total_models": total, "models_on_rank0": len(mine), "columns_on_rank0": R, "jackknife": True,
+           "config": "BASELINE config 5: 300x300x300 fp64, 2048 jackknife models (jk = mode 0, fiber m mod 300), "
+                     "model m -> GPU m mod N, line search on"}
+    if ks.ttm_launches:
+        ms = ks.ttm_ms / ks.ttm_launches
+        out["ttm_kernel"] = {"launches": ks.ttm_launches, "avg_launch_ms": round(ms, 4),
+                             "achieved_tflops": round(ks.ttm_flops / ks.ttm_launches / (ms * 1e-3) * 1e-12, 3)}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -120,13 +194,17 @@ def main():
     ap.add_argument("--steady-steps", type=int, default=200,
                     help="further sweeps timed after the K steps for the `steady_state` field (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=0)
-    ap.add_argument("--cpu-protocol", default="bounded", choices=["bounded", "full"])
+    ap.add_argument("--cpu-protocol", default="middle", choices=["bounded", "middle", "full"])
+    ap.add_argument("--no-strong-leg", action="store_true",
+                    help="c3 only: skip the strong-scaling config-5 job (`strong_c5`) timed after the weak one")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL) for real multi-GPU runs; gloo only to rehearse the N>1 path")
     ap.add_argument("--force-device0", action="store_true",
                     help="rehearsal on a 1-GPU box: every rank uses cuda:0 (use with --dist-backend gloo)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))
 
     import numpy as np  # noqa: F401
     import torch
@@ -138,9 +216,6 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d "
-                             "--master-addr 127.0.0.1 --master-port P bench.py --gpus %d ..." % (args.gpus, args.gpus))
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the CALS engine has no CPU fallback")
@@ -321,6 +396,10 @@ def main():
                      "ms_per_step_per_rank": per_rank_ms},
         }
     eng.close()
+    if args.workload == "c3" and not args.no_strong_leg:
+        leg = strong_c5_leg(cc, inputs, sharding, torch, X, world, rank, local_rank, args.steps, args.warmup, red_dev)
+        if rank == 0:
+            out["strong_c5"] = leg
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload != "c5":
         threads = args.cpu_threads or min(len(os.sched_getaffinity(0)), 16)
         out["cpu_baseline"] = cpu_baseline(modes, ranks, X, base, jk, ls, threads, args.cpu_protocol)

@@ -75,7 +75,7 @@ EXPORTS = [
     "cals_hip_model_result", "cals_hip_admit", "cals_hip_sweep", "cals_hip_evict",
     "cals_hip_step", "cals_hip_get_report",
     "cals_hip_active_cols", "cals_hip_models_in_flight", "cals_hip_queue_size",
-    "cals_hip_synchronize", "cals_hip_debug_mttkrp", "cals_hip_debug_mttkrp_path", "cals_hip_debug_get_factor",
+    "cals_hip_synchronize", "cals_hip_mttkrp", "cals_hip_debug_mttkrp", "cals_hip_debug_mttkrp_path", "cals_hip_debug_get_factor",
     "cals_hip_debug_get_lambda", "cals_hip_debug_get_gramian", "cals_hip_debug_model_status",
     "cals_hip_debug_get_norms", "cals_hip_set_profiling", "cals_hip_get_kernel_stats",
     "cals_hip_reset_kernel_stats", "cals_hip_stream", "cals_hip_device_count",
@@ -113,6 +113,7 @@ def load_library():
     lib.cals_hip_last_error.argtypes = [vp]
     lib.cals_hip_last_error.restype = C.c_char_p
     lib.cals_hip_set_tensor.argtypes = [vp, dp]
+    lib.cals_hip_mttkrp.argtypes = [vp, i64, C.POINTER(dp), C.c_int, dp, C.POINTER(C.c_double)]
     lib.cals_hip_set_params.argtypes = [vp, C.POINTER(Params)]
     lib.cals_hip_enqueue.argtypes = [vp, i64, C.POINTER(dp), dp, C.c_int, i64, C.POINTER(i64)]
     lib.cals_hip_run.argtypes = [vp, C.POINTER(Report)]
@@ -335,6 +336,17 @@ class Engine:
     @property
     def queue_size(self):
         return int(self.lib.cals_hip_queue_size(self.h))
+
+    def mttkrp(self, factors, mode):
+        """cals_hip_mttkrp: the MTTKRP of `mode` for ONE Ktensor given by host factors (mttkrp::mttkrp,
+        src/utils/mttkrp.cpp:562-614) on an idle engine.  Returns (G [I_mode x rank], device milliseconds)."""
+        fs = [np.asfortranarray(f, dtype=np.float64) for f in factors]
+        rank = fs[0].shape[1]
+        G = np.zeros((self.modes[mode], rank), order="F")
+        arr = (C.POINTER(C.c_double) * len(fs))(*[_dp(f) for f in fs])
+        ms = C.c_double(0.0)
+        self._chk(self.lib.cals_hip_mttkrp(self.h, C.c_int64(rank), arr, int(mode), _dp(G), C.byref(ms)))
+        return G, ms.value
 
     def debug_mttkrp(self, mode, path=None):
         """path: None = the path a sweep takes under the engine's plan; "plain" | "first" | "second"

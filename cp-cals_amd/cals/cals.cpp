@@ -86,8 +86,13 @@ class EngineLease {
   static cals_hip_engine *build(const Tensor &X, int64_t buffer_size, int device, int dtype) {
     std::vector<int64_t> modes(X.get_modes().begin(), X.get_modes().end());
     cals_hip_engine *eng = nullptr;
-    int rc = cals_hip_create_ex(&eng, (int)modes.size(), modes.data(), buffer_size, device, dtype);
+    // capacity = whole 128-column blocks (the device buffers are sized in those anyway): a loop of calls with
+    // growing widths -- cp_als over ascending ranks, as the driver runs it -- then re-targets ONE engine
+    // (cals_hip_rebind) instead of rebuilding it and uploading X again on every call
+    const int64_t capacity = (buffer_size + 127) / 128 * 128;
+    int rc = cals_hip_create_ex(&eng, (int)modes.size(), modes.data(), capacity, device, dtype);
     if (rc == 0) rc = cals_hip_set_tensor(eng, X.get_data());
+    if (rc == 0 && capacity != buffer_size) rc = cals_hip_rebind(eng, buffer_size);
     if (rc) {
       const std::string msg = eng ? cals_hip_last_error(eng) : "no engine";
       if (eng) cals_hip_destroy(eng);
@@ -116,17 +121,19 @@ class EngineLease {
                         mirror->slots.end());
     for (auto &s : mirror->slots) {
       if (s.busy || s.device != device || s.dtype != dtype) continue;
-      if (s.data != X.get_data() || s.print != print) {  // X was rewritten behind the mirror: upload again
-        const int rc = cals_hip_set_tensor(s.engine, X.get_data());
-        if (rc) fail(s.engine, "cals_hip_set_tensor", rc);
-        s.data = X.get_data();
-        s.print = print;
-      }
       if (cals_hip_capacity(s.engine) < buffer_size) {  // this call needs wider buffers: replace the engine
-        cals_hip_destroy(s.engine);
+        cals_hip_destroy(s.engine);                       // (build uploads the current X: no re-upload first)
         s.engine = nullptr;
         s.engine = build(X, buffer_size, device, dtype);
+        s.data = X.get_data();
+        s.print = print;
       } else {
+        if (s.data != X.get_data() || s.print != print) {  // X was rewritten behind the mirror: upload again
+          const int rc = cals_hip_set_tensor(s.engine, X.get_data());
+          if (rc) fail(s.engine, "cals_hip_set_tensor", rc);
+          s.data = X.get_data();
+          s.print = print;
+        }
         const int rc = cals_hip_rebind(s.engine, buffer_size);
         if (rc) fail(s.engine, "cals_hip_rebind", rc);
       }
@@ -291,6 +298,32 @@ void cp_cals_devices(const Tensor &X, std::vector<std::reference_wrapper<Ktensor
   }
 }
 }  // namespace
+
+namespace mttkrp {
+// see utils/mttkrp.h; include/utils/mttkrp.h:77-81, src/utils/mttkrp.cpp:562-614
+Matrix &mttkrp(const Tensor &X, Ktensor &u, std::vector<Matrix> &workspace, dim_t mode, MttkrpParams &params) {
+  (void)workspace;
+  const dim_t n_modes = X.get_n_modes();
+  if (mode >= n_modes) throw std::runtime_error("mttkrp: mode out of range");
+  if (u.get_factors().size() != n_modes) throw std::runtime_error("mttkrp: Ktensor and Tensor differ in modes");
+  const dim_t r = u.get_components();
+  EngineLease lease(X, (int64_t)r, 0, CALS_HIP_F64, true);
+  std::vector<const double *> f(n_modes);
+  for (dim_t n = 0; n < n_modes; n++) f[n] = u.get_factor(n).get_data();
+  Matrix &G = u.get_factor(mode);
+  double ms = 0.0;
+  const int rc = cals_hip_mttkrp(lease.get(), (int64_t)r, f.data(), (int)mode, G.get_data(), &ms);
+  if (rc) fail(lease.get(), "cals_hip_mttkrp", rc);
+  lease.done();
+  for (int i = 0; i < MttkrpTimers::LENGTH; i++) params.mttkrp_timers.timers[i].reset();
+  params.mttkrp_timers.timers[MttkrpTimers::MT_GEMM].set_time(ms * 1e-3);
+  uint64_t in_out = 0;
+  for (dim_t n = 0; n < n_modes; n++) in_out += (uint64_t)X.get_modes()[n] * r;
+  params.flops = 2ull * (uint64_t)X.get_n_elements() * r;
+  params.memops = (uint64_t)X.get_n_elements() + in_out;
+  return G;
+}
+}  // namespace mttkrp
 
 void CalsParams::print() const {
   using std::cout;

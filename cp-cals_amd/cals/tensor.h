@@ -122,6 +122,12 @@ class Tensor {
   [[nodiscard]] dim_t get_n_modes() const noexcept { return static_cast<dim_t>(modes.size()); }
   [[nodiscard]] const vector<dim_t> &get_modes() const noexcept { return modes; }
   [[nodiscard]] double *get_data() const noexcept { return data; }
+  // writable access through a non-const Tensor: whatever the caller does with the pointer, the device copy can
+  // no longer be trusted (the reference's default path always reads the current host data)
+  [[nodiscard]] double *get_data() noexcept {
+    mirror.reset();
+    return data;
+  }
   [[nodiscard]] int get_rank() const noexcept { return rank; }
   void set_rank(int r) noexcept { rank = r; }
 
@@ -138,7 +144,10 @@ class Tensor {
   [[nodiscard]] bool is_view() const noexcept { return data_up == nullptr; }
 
   double const &operator[](dim_t index) const noexcept { return data[index]; }
-  double &operator[](dim_t index) noexcept { return data[index]; }
+  double &operator[](dim_t index) noexcept {
+    mirror.reset();  // see get_data()
+    return data[index];
+  }
 
   // "soft" resize inside the memory the tensor was created with
   void resize(dim_t new_n_elements, vector<dim_t> &new_modes) {
@@ -186,9 +195,10 @@ class Tensor {
   [[nodiscard]] Unfolding implicit_unfold(dim_t mode) const;
 
   // ---- device mirror (counterpart of get_cudata / allocate_cudata / send_to_device) ----
-  // The mirror is dropped by every member that rewrites the data or re-points it; a caller that writes
-  // through get_data() / operator[] between two cp_cals calls says so with invalidate_device_mirror()
-  // (cp_cals also compares a sampled fingerprint of the data and re-uploads when it changed).
+  // The mirror is dropped by every member that rewrites the data, re-points it or hands out writable access
+  // (non-const get_data() / operator[]); a caller that writes through a pointer obtained EARLIER, or through
+  // the const overload's pointer, says so with invalidate_device_mirror() (cp_cals also compares a sampled
+  // fingerprint of the data and re-uploads when it changed).
   [[nodiscard]] std::shared_ptr<DeviceMirror> &device_mirror() const noexcept { return mirror; }
   void invalidate_device_mirror() const noexcept { mirror.reset(); }
 };

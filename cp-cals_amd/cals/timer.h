@@ -17,6 +17,7 @@ class Timer {
   void start() { t0 = clock::now(); }
   void stop() { seconds = std::chrono::duration<double>(clock::now() - t0).count(); }
   void reset() { seconds = 0.0; }
+  void set_time(double s) { seconds = s; }  // extension: slots filled from device event pairs
   [[nodiscard]] double get_time() const { return seconds < 0.0 ? 0.0 : seconds; }
 };
 

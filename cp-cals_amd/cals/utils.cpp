@@ -115,6 +115,16 @@ double compute_error(const Tensor &X, const Ktensor &ktensor) {
   for (dim_t i = 0; i < X.get_n_elements(); i++) s += (X[i] - R[i]) * (X[i] - R[i]);
   return std::sqrt(s);
 }
+double compute_fast_error(double X_norm, const std::vector<double> &lambda, const Matrix &last_factor,
+                          const Matrix &last_mttkrp, const Matrix &gramian_hadamard) {
+  double term2 = 0.0;  // sum of lambda_i lambda_j H_ij, column by column (error.cpp:71-74)
+  for (dim_t j = 0; j < gramian_hadamard.get_cols(); j++)
+    for (dim_t i = 0; i < gramian_hadamard.get_rows(); i++) term2 += lambda[i] * lambda[j] * gramian_hadamard(i, j);
+  double term3 = 0.0;  // <A diag(lambda), G> (error.cpp:77-80)
+  for (dim_t j = 0; j < last_factor.get_cols(); j++)
+    for (dim_t i = 0; i < last_factor.get_rows(); i++) term3 += lambda[j] * last_factor(i, j) * last_mttkrp(i, j);
+  return std::sqrt(std::fmax(X_norm * X_norm + term2 - 2 * term3, 0.0));
+}
 }  // namespace error
 
 namespace ops {

@@ -41,6 +41,15 @@ struct MttkrpParams {
   uint64_t memops{0};
 };
 
+// mttkrp::mttkrp (include/utils/mttkrp.h:77-81, src/utils/mttkrp.cpp:562-614): the MTTKRP of `mode` from the other
+// factors of u, written into u's factor `mode` (returned) -- here ONE launch of the fused MTTKRP kernel + the split
+// reduction on an engine leased from X's device mirror (cals_hip_mttkrp).  `workspace` is accepted and unused (no
+// Khatri-Rao product is materialised), `params.method` / `lut` have no effect; params.flops / memops are the
+// algorithmic counts (2 * prod(I) * R flop; |X| + sum_n I_n R elements) and the timers carry the device time of the
+// launch in MT_GEMM (others 0).  This is the callable include/experiments/bench_mttkrp_cals.h:49-84 times.
+cals::Matrix &mttkrp(const cals::Tensor &X, cals::Ktensor &u, std::vector<cals::Matrix> &workspace, dim_t mode,
+                     cals::mttkrp::MttkrpParams &params);
+
 // include/utils/mttkrp.h:100-101.  The tables under data/<BACKEND>/lookup_tables are tuned for MKL / V100
 // variants that do not exist here: always returns an empty table (and never warns).
 MttkrpLut read_lookup_table(std::vector<dim_t> const &modes, int threads, bool gpu = false, bool suppress_warning = false);

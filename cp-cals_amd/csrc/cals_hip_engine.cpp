@@ -1497,14 +1497,21 @@ int cals_hip_create_ex(cals_hip_engine **out, int n_modes, const int64_t *modes,
                             // leaves behind (patched, not recomputed).  Both constants checked against the
                             // measured best plan of 14 shapes (tools/plan_scan.py, profiles/r02_plan_scan.txt)
                             0.52 * (pair_cost(0) + pair_cost(1) + pair_cost(2))};
+    // a pair whose T slab of 16 columns outgrows the TTM's 32-bit store offsets is not planned
+    auto pair_ok = [&](int first) {
+      return ttm_shape_ok(modes[(first + 1) % 3], round_up((int)modes[first], 16), e->dtype);
+    };
+    const bool plan_ok[4] = {true, pair_ok(0), pair_ok(1), pair_ok(0) && pair_ok(1) && pair_ok(2)};
     int choice = 0;
     for (int k = 1; k < 4; k++)
-      if (cost[k] < 0.97 * c_plain && cost[k] < cost[choice]) choice = k;
+      if (plan_ok[k] && cost[k] < 0.97 * c_plain && cost[k] < cost[choice]) choice = k;
     if (const char *v = getenv("CALS_HIP_TREE")) {
-      if (v[0] == '0') choice = 0;
-      else if (v[0] == 'A' || v[0] == 'a' || v[0] == '1') choice = 1;
-      else if (v[0] == 'B' || v[0] == 'b' || v[0] == '2') choice = 2;
-      else if (v[0] == 'M' || v[0] == 'm' || v[0] == '3') choice = 3;
+      int forced = choice;
+      if (v[0] == '0') forced = 0;
+      else if (v[0] == 'A' || v[0] == 'a' || v[0] == '1') forced = 1;
+      else if (v[0] == 'B' || v[0] == 'b' || v[0] == '2') forced = 2;
+      else if (v[0] == 'M' || v[0] == 'm' || v[0] == '3') forced = 3;
+      if (plan_ok[forced]) choice = forced;
     }
     if (choice) {
       TreePlan &tp = e->tree;
@@ -1719,6 +1726,13 @@ int cals_hip_rebind(cals_hip_engine *e, int64_t buffer_size) {
   e->slots_dirty = true;
   e->n_ktensors = e->comp_sum = e->ls_performed = e->ls_failed = 0;
   e->changed_deferred = false;
+  // a binding is a fresh run: nothing of the previous one may show up in its report (cals_hip_get_report's
+  // iter = sweeps, the sticky NNLS status word) or in its sweep log
+  e->sweeps = 0;
+  e->log_base = 0;
+  e->sweep_log.clear();
+  e->nnls_status = 0;
+  if (e->d_nnls_status) HIPCHK(hipMemsetAsync(e->d_nnls_status, 0, sizeof(int), e->stream));
   tree_invalidate(e);
   adjust_edges(e);
   return CALS_HIP_OK;
@@ -1932,6 +1946,12 @@ int cals_hip_set_params(cals_hip_engine *e, const cals_hip_params *p) {
     return fail(e, CALS_HIP_ERR_ARG, "line_search_method: 0 = NO_ERROR_CHECKING, 1 | 2 = ERROR_CHECKING");
   if (p->line_search && p->line_search_method != e->prm.line_search_method && !e->registry.empty())
     return fail(e, CALS_HIP_ERR_STATE, "the line-search method cannot change while models are in flight");
+  // ls::ERROR_CHECKING_SERIAL evaluates a candidate with error::compute_error, which rebuilds the tensor from
+  // factors 0, 1, 2 only and subtracts it from ALL elements of X (src/utils/error.cpp:7-30): for N > 3 the
+  // reference reads past its workspace -- undefined behaviour, nothing to match, so the combination is refused
+  if (p->line_search && p->line_search_method == 1 && e->n_modes > 3)
+    return fail(e, CALS_HIP_ERR_ARG,
+                "ERROR_CHECKING_SERIAL line search is defined for 3-way tensors only (src/utils/error.cpp:7-30)");
   if (p->line_search && p->line_search_interval < 1)
     return fail(e, CALS_HIP_ERR_ARG, "line_search_interval must be >= 1");
   if (p->update_method < 0 || p->update_method > 1)
@@ -2237,6 +2257,66 @@ int cals_hip_debug_mttkrp_path(cals_hip_engine *e, int mode, int path, double *G
       G_host[i + I * c] = s;
     }
   return CALS_HIP_OK;
+}
+
+int cals_hip_mttkrp(cals_hip_engine *e, int64_t rank, const double *const *factors, int mode, double *G_host,
+                    double *device_ms) {
+  if (!e || !factors || !G_host || mode < 0 || mode >= e->n_modes) return CALS_HIP_ERR_ARG;
+  HIPCHK(hipSetDevice(e->device));
+  if (!e->has_tensor) return fail(e, CALS_HIP_ERR_STATE, "set_tensor first");
+  if (!e->registry.empty() || !e->queue.empty())
+    return fail(e, CALS_HIP_ERR_STATE, "cals_hip_mttkrp: the engine must be idle (models are queued or in flight)");
+  if (rank < 1 || rank > e->buffer) return fail(e, CALS_HIP_ERR_ARG, "cals_hip_mttkrp: rank must be in [1, buffer_size]");
+  int rc = flush_pending_out(e);
+  if (rc) return rc;
+  // the Ktensor's factors into columns [0, rank) of the (all-zero) multi-factor buffers
+  std::vector<std::vector<float>> f32((size_t)e->n_modes);
+  for (int n = 0; n < e->n_modes; n++) {
+    if (n == mode) continue;
+    if (!factors[n]) return fail(e, CALS_HIP_ERR_ARG, "null factor pointer");
+    const size_t ne = (size_t)(e->modes[n] * rank);
+    const void *src = factors[n];
+    if (e->dtype == CALS_F32) {
+      f32[(size_t)n].resize(ne);
+      for (size_t i = 0; i < ne; i++) f32[(size_t)n][i] = (float)factors[n][i];
+      src = f32[(size_t)n].data();
+    }
+    HIPCHK(hipMemcpyAsync(e->factor[n], src, ne * e->es, hipMemcpyHostToDevice, e->stream));
+  }
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  if (device_ms) {
+    HIPCHK(hipEventCreate(&ev0));
+    HIPCHK(hipEventCreate(&ev1));
+    HIPCHK(hipEventRecord(ev0, e->stream));
+  }
+  Geo g{0, 0};
+  rc = launch_mttkrp(e, mode, rank, &g);
+  if (!rc) {
+    const hipError_t he = reduce_partials_launch(e->partial, g.T, e->lay[mode].ldPart, (int)e->modes[mode], (int)rank,
+                                                 e->factor[mode], e->dtype, e->stream);
+    if (he != hipSuccess) rc = fail(e, CALS_HIP_ERR_HIP, hipGetErrorString(he));
+  }
+  if (device_ms && !rc) HIPCHK(hipEventRecord(ev1, e->stream));
+  const size_t ng = (size_t)(e->modes[mode] * rank);
+  std::vector<float> gf;
+  if (!rc) {
+    if (e->dtype == CALS_F32) gf.resize(ng);
+    HIPCHK(hipMemcpyAsync(e->dtype == CALS_F32 ? (void *)gf.data() : (void *)G_host, e->factor[mode], ng * e->es,
+                          hipMemcpyDeviceToHost, e->stream));
+  }
+  // leave the buffers as found: free columns are zero (multi_ktensor.cpp:132-163)
+  for (int n = 0; n < e->n_modes; n++)
+    HIPCHK(hipMemsetAsync(e->factor[n], 0, (size_t)(e->modes[n] * rank) * e->es, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  for (size_t i = 0; i < gf.size(); i++) G_host[i] = (double)gf[i];
+  if (device_ms) {
+    float ms = 0.f;
+    if (!rc) HIPCHK(hipEventElapsedTime(&ms, ev0, ev1));
+    *device_ms = (double)ms;
+    (void)hipEventDestroy(ev0);
+    (void)hipEventDestroy(ev1);
+  }
+  return rc;
 }
 
 int cals_hip_debug_get_factor(cals_hip_engine *e, int mode, double *host) {

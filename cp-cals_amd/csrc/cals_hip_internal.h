@@ -95,6 +95,7 @@ struct TtmArgs {
   unsigned long long *dbg_trace;  // CALS_DIAG builds + CALS_TTM_TRACE=1: per-stage clock stamps
 };
 int ttm_max_mt(int dtype);
+bool ttm_shape_ok(long long S, long long Mp, int dtype);  // the TTM's 32-bit T store offsets cover this pair
 hipError_t ttm_launch(const TtmArgs &a, hipStream_t st);
 hipError_t pack_pt_launch(const void *P, long long ldP, int A, int Ap, int NB, int R, void *Pt,
                           int dtype, hipStream_t st);

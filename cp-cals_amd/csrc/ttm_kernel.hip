@@ -59,6 +59,9 @@ struct TtmCfg {
 #ifndef CALS_TTM_RING
 #define CALS_TTM_RING 6
 #endif
+#ifndef CALS_TTM_ROLL
+#define CALS_TTM_ROLL 1  // fp64: rolling T flush inside the first stage of the next s (see TtmBody)
+#endif
   static constexpr int RING = (ES == 4) ? 8 : CALS_TTM_RING;
   static constexpr int D = N < RING ? N : RING;      // operand ring depth
   static constexpr int H = N / 2;                    // barrier position
@@ -70,10 +73,12 @@ template <int MT, typename T>
 struct TtmPipe {
   typedef TtmCfg<MT, T> C;
   typedef typename Acc<T>::type acc_t;
-  template <int I>
+  // EXTRA: LDS reads issued behind the ring read that step I consumes, besides the ring's own (the rolling
+  // flush reads the stage's Q values mid-stream)
+  template <int I, int EXTRA = 0>
   static __device__ __forceinline__ void step(acc_t (&acc)[MT], T (&ring)[C::D], const T (&bq)[4],
                                               unsigned base) {
-    constexpr int outstanding = (C::D - 1 < C::N - 1 - I) ? C::D - 1 : C::N - 1 - I;
+    constexpr int outstanding = ((C::D - 1 < C::N - 1 - I) ? C::D - 1 : C::N - 1 - I) + EXTRA;
     asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(outstanding));
     __builtin_amdgcn_sched_barrier(0);
     constexpr int q = I / MT, t = I % MT;
@@ -132,7 +137,9 @@ static __device__ __forceinline__ void run(const TtmArgs &a, const int m0, const
   }
 
   // ---- per-lane DMA source offsets (stage independent) ----
-  long long src_off[C::NP];
+  // 32-bit BYTE offsets from wave-uniform bases: the DMA instructions take the scalar-base form
+  // (global_load_lds_dwordx4 v_off, s[base:base+1]) -- no 64-bit VALU add and no address pair per piece
+  unsigned src_off[C::NP];
 #pragma unroll
   for (int k = 0; k < C::NP; ++k) {
     const int piece = k * 8 + wave;
@@ -141,15 +148,16 @@ static __device__ __forceinline__ void run(const TtmArgs &a, const int m0, const
     const int m = e - acol * C::LDL;
     int gm = m0 + m;
     gm = gm < a.Mp ? gm : 0;  // rows past the padded tensor: any valid address, unused
-    src_off[k] = gm + (long long)a.Mp * acol;
+    src_off[k] = (unsigned)(gm + a.Mp * acol) * (unsigned)C::ES;  // < 16 Mp elements
   }
-  int p_src[C::NPP], p_dst[C::NPP];
+  unsigned p_src[C::NPP];
+  int p_dst[C::NPP];
 #pragma unroll
   for (int k = 0; k < C::NPP; ++k) {
     const int pp = k * 8 + wave;       // P instruction pp: row pp / PPR, columns (pp % PPR) * PPE ...
     const int row = pp / C::PPR;
     const int c0 = (pp % C::PPR) * C::PPE;
-    p_src[k] = row * CALS_BN + c0 + lane * (C::PLB / C::ES);
+    p_src[k] = (unsigned)(row * CALS_BN + c0 + lane * (C::PLB / C::ES)) * (unsigned)C::ES;
     p_dst[k] = C::POFF + row * C::PP + c0;
   }
   long long q_off;
@@ -168,13 +176,15 @@ static __device__ __forceinline__ void run(const TtmArgs &a, const int m0, const
     if constexpr (K < C::NP) {
       const int piece = K * 8 + wave;
       if (piece < C::PIECES && !DIAG(a.dbg & 16))  // CALS_DIAG, dbg 16 (timing only): no X DMA
-        __builtin_amdgcn_global_load_lds((const GLOBAL_AS void *)(src_slab + src_off[K]),
-                                         (LDS_AS void *)(dst + piece * C::PE), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(
+            (const GLOBAL_AS void *)(reinterpret_cast<const char *>(src_slab) + (unsigned long long)src_off[K]),
+            (LDS_AS void *)(dst + piece * C::PE), 16, 0, 0);
     } else if constexpr (K < C::NP + C::NPP) {
       constexpr int k = K - C::NP;
       if (!DIAG(a.dbg & 8))  // CALS_DIAG, dbg 8 (timing only): no P DMA
-      __builtin_amdgcn_global_load_lds((const GLOBAL_AS void *)(p_slab + p_src[k]),
-                                       (LDS_AS void *)(dst + p_dst[k]), C::PLB, 0, 0);
+      __builtin_amdgcn_global_load_lds(
+          (const GLOBAL_AS void *)(reinterpret_cast<const char *>(p_slab) + (unsigned long long)p_src[k]),
+          (LDS_AS void *)(dst + p_dst[k]), C::PLB, 0, 0);
     } else if (wave < C::QPIECES) {
       const char *src = (const char *)(q_row + q_off) + q_byte;
       __builtin_amdgcn_global_load_lds((const GLOBAL_AS void *)src,
@@ -240,6 +250,14 @@ static __device__ __forceinline__ void run(const TtmArgs &a, const int m0, const
     const int gc = nb * CALS_BN + wave * 16 + krow + 4 * r;
     tc[r] = Tout + ((long long)gc * S) * a.Mp + m0 + lcol;
   }
+  // fp64 rolling flush: the same addresses as a wave-uniform base (SGPR pair, carries s) + a 32-bit per-lane
+  // byte offset per register r (ttm_launch checks 15 * S * Mp * 8 + 8 * Mp < 2^32)
+  constexpr bool ROLL = (C::ES == 8) && (CALS_TTM_ROLL != 0);
+  unsigned tvo[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) tvo[r] = (unsigned)((((long long)(krow + 4 * r) * S) * a.Mp + lcol) * C::ES);
+  const char *const t_wave = reinterpret_cast<const char *>(Tout) +
+                             (((long long)(nb * CALS_BN + wave * 16) * S) * a.Mp + m0) * C::ES;
   // fp32: T flush through a per-wave LDS staging tile (two tiles = 32 rows = one 128-byte line per
   // column), so that every global_store_dwordx4 writes 8 whole lines
   T *const stg = lds + 3 * C::BUF + wave * C::STG;
@@ -378,19 +396,23 @@ static __device__ __forceinline__ void run(const TtmArgs &a, const int m0, const
           }
           dg_last = d2;
         }
-        if (pend) {
-          flush(s_pend, q_pend);
-          pend = false;
+        if constexpr (!ROLL) {
+          if (pend) {
+            flush(s_pend, q_pend);
+            pend = false;
+          }
         }
       }
       T ring[C::D];
       T qcur[C::NQ];
       T bq[4];
-      lds_read_off<T, 0>(qcur[0], bufb + q_lane_off);
-      if constexpr (C::NQ == 4) {  // fp64: Q[s, krow + 4r]
-        lds_read_off<T, 4 * C::ES>(qcur[1], bufb + q_lane_off);
-        lds_read_off<T, 8 * C::ES>(qcur[2], bufb + q_lane_off);
-        lds_read_off<T, 12 * C::ES>(qcur[3], bufb + q_lane_off);
+      if constexpr (!ROLL) {
+        lds_read_off<T, 0>(qcur[0], bufb + q_lane_off);
+        if constexpr (C::NQ == 4) {  // fp64: Q[s, krow + 4r]
+          lds_read_off<T, 4 * C::ES>(qcur[1], bufb + q_lane_off);
+          lds_read_off<T, 8 * C::ES>(qcur[2], bufb + q_lane_off);
+          lds_read_off<T, 12 * C::ES>(qcur[3], bufb + q_lane_off);
+        }
       }
       lds_read_off<T, 0>(bq[0], bufb + p_lane_off);
       lds_read_off<T, 4 * C::PP * C::ES>(bq[1], bufb + p_lane_off);
@@ -400,10 +422,41 @@ static __device__ __forceinline__ void run(const TtmArgs &a, const int m0, const
       asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(C::D));  // Q and P landed (D younger reads in flight)
       __builtin_amdgcn_sched_barrier(0);
 
+      // ROLL: `pend` = this is the first stage of a new s and the finished tiles of the previous s are still
+      // in tacc.  Tile t is flushed (G += T * Q[s_prev], T -> HBM, T = 0) right in front of the k-step-0 MFMA
+      // that starts it anew: the 4 FMAs + 4 stores + 4 moves of a tile sit between two MFMAs instead of 120
+      // instructions in a row behind the stage.  q_pend is the ONE set of Q registers:
+      // every stage reads its Q[s, :] into it right behind k-step 0 -- i.e. behind the last use of the previous
+      // s's values -- so during k-step 0 of a new s it still holds Q[s - 1, :].
+      constexpr int QJ = MT - 1;  // the step behind whose ring read the Q reads are issued
+      const bool roll = ROLL && pend;
+      const char *const t_s = t_wave + ((long long)s_pend * a.Mp) * C::ES;
       [&]<int... Is>(std::integer_sequence<int, Is...>) {
         (
             [&] {
-              P3::template step<Is>(tacc, ring, bq, base);
+              if constexpr (ROLL && Is < MT) {
+                if (roll) {
+#pragma unroll
+                  for (int r = 0; r < 4; ++r) {
+                    gacc[Is][r] += tacc[Is][r] * q_pend[r];
+                    if (st)
+                      asm volatile("global_store_dwordx2 %0, %1, %2 offset:%3 nt"
+                                   :: "v"(tvo[r]), "v"(tacc[Is][r]), "s"(t_s), "i"(16 * Is * C::ES) : "memory");
+                  }
+                  // (the MFMA's inline constant C = 0 would save these four moves, but as inline asm with the tile
+                  // tied in place the allocator copies tiles through a second register set: 130 spills at MT 10)
+                  tacc[Is] = (acc_t){0, 0, 0, 0};
+                }
+                P3::template step<Is>(tacc, ring, bq, base);
+                if constexpr (Is == QJ) {
+                  lds_read_off<T, 0>(q_pend[0], bufb + q_lane_off);
+                  lds_read_off<T, 4 * C::ES>(q_pend[1], bufb + q_lane_off);
+                  lds_read_off<T, 8 * C::ES>(q_pend[2], bufb + q_lane_off);
+                  lds_read_off<T, 12 * C::ES>(q_pend[3], bufb + q_lane_off);
+                }
+              } else {
+                P3::template step<Is, (ROLL && Is > QJ && Is <= QJ + C::D) ? 4 : 0>(tacc, ring, bq, base);
+              }
               if constexpr (LATE && Is < C::HH) {
                 if (ALWAYS || fetch) issue_at.template operator()<Is>(dma_x, dma_p, dma_q, dst);
               }
@@ -435,7 +488,7 @@ static __device__ __forceinline__ void run(const TtmArgs &a, const int m0, const
         (
             [&] {
               constexpr int J = I0 + Is;  // step H + J
-              P3::template step<C::H + J>(tacc, ring, bq, base);
+              P3::template step<C::H + J, (ROLL && C::H + J <= QJ + C::D) ? 4 : 0>(tacc, ring, bq, base);
               if constexpr (!LATE && J < C::HH) {
                 if (ALWAYS || fetch) issue_at.template operator()<J>(dma_x, dma_p, dma_q, dst);
               }
@@ -452,12 +505,15 @@ static __device__ __forceinline__ void run(const TtmArgs &a, const int m0, const
       else  // the operand reads already issued for k-step 3 must land before their registers are reused
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
+      if constexpr (ROLL) pend = false;
       if (ab_c == nAb - 1) {
-        if constexpr (LATE) {
+        if constexpr (LATE || ROLL) {
           pend = true;
           s_pend = s_c;
+          if constexpr (!ROLL) {
 #pragma unroll
-          for (int r = 0; r < C::NQ; ++r) q_pend[r] = qcur[r];
+            for (int r = 0; r < C::NQ; ++r) q_pend[r] = qcur[r];
+          }
         } else {
           flush(s_c, qcur);
         }
@@ -469,7 +525,22 @@ static __device__ __forceinline__ void run(const TtmArgs &a, const int m0, const
       ab_c = ab_c + 1;
       if (ab_c >= nAb) { ab_c = 0; s_c++; }
     }
-    if constexpr (LATE) {
+    if constexpr (ROLL) {  // the last s of the range: nothing overwrites its tiles, flush them here
+      if (pend) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const char *const t_s = t_wave + ((long long)s_pend * a.Mp) * C::ES;
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            gacc[t][r] += tacc[t][r] * q_pend[r];
+            if (st)
+              asm volatile("global_store_dwordx2 %0, %1, %2 offset:%3 nt"
+                           :: "v"(tvo[r]), "v"(tacc[t][r]), "s"(t_s), "i"(16 * t * C::ES) : "memory");
+          }
+        }
+      }
+    } else if constexpr (LATE) {
       if (pend) flush(s_pend, q_pend);
     }
     if (DIAG(trace)) {  // stamps stay in registers inside the loop (a global store per stage would sit
@@ -551,9 +622,17 @@ static hipError_t ttm_launch_mt(const TtmArgs &a, hipStream_t st) {
 
 int ttm_max_mt(int dtype) { return dtype == CALS_F32 ? 20 : 10; }
 
+// fp64: the rolling T flush addresses a wave's 16 columns of T by a 32-bit per-lane byte offset from a
+// wave-uniform base: (15 S + 1) Mp elements must stay below 2^32 bytes (the engine plans no pair beyond that)
+bool ttm_shape_ok(long long S, long long Mp, int dtype) {
+  if (dtype == CALS_F32) return true;
+  return (15 * S + 1) * Mp * 8 < (1ll << 32);
+}
+
 hipError_t ttm_launch(const TtmArgs &a, hipStream_t st) {
   if (a.MT < 1 || a.MT > ttm_max_mt(a.dtype)) return hipErrorInvalidValue;
   if (a.S >= (1ll << 31) / (a.Ap >> 4 ? a.Ap >> 4 : 1)) return hipErrorInvalidValue;  // 32-bit stage counters
+  if (!ttm_shape_ok(a.S, a.Mp, a.dtype)) return hipErrorInvalidValue;
   if (a.dtype == CALS_F32) {
     switch (a.MT) {
 #define CASE(N) case N: return ttm_launch_mt<N, float>(a, st);

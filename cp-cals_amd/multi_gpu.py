@@ -20,18 +20,27 @@ import torch.distributed as dist
 class WorkQueue:
     """Indices 0 .. n_items-1 handed out in claim order through an atomic counter on a TCPStore."""
 
+    _instances = 0  # queues are constructed collectively (every rank, same order): the n-th one everywhere
+
     def __init__(self, n_items, name="cals_work_queue", store=None, port=None):
         """store: any torch.distributed store with add(); default = the process group's own rendezvous
         store behind a prefix (no extra port).  port: only if that store is not reachable -- a TCPStore on
-        MASTER_ADDR:port, chosen by the caller (never guessed from MASTER_PORT)."""
+        MASTER_ADDR:port, chosen by the caller (never guessed from MASTER_PORT).  Construct queues in the same
+        order on every rank: each instance counts under its own key prefix, so a second queue of the same name
+        in one job starts at 0 again instead of at the first one's final value."""
         self.n = int(n_items)
         self.key = name
         self._local = 0  # single-process fall-back
         self.store = store
+        WorkQueue._instances += 1
         if self.store is None and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             if port is None:
-                base = dist.distributed_c10d._get_default_store()
-                self.store = dist.PrefixStore("cals_work_queue/" + name, base)
+                get_store = getattr(dist.distributed_c10d, "_get_default_store", None)
+                if get_store is None:
+                    raise RuntimeError("this torch build does not expose the process group's store "
+                                       "(distributed_c10d._get_default_store): pass store= or port= to WorkQueue")
+                base = get_store()
+                self.store = dist.PrefixStore("cals_work_queue/%d/%s" % (WorkQueue._instances, name), base)
             else:
                 host = os.environ.get("MASTER_ADDR", "127.0.0.1")
                 self.store = dist.TCPStore(host, int(port), dist.get_world_size(), is_master=(dist.get_rank() == 0),

@@ -215,6 +215,16 @@ int64_t cals_hip_models_in_flight(const cals_hip_engine *e);
 int64_t cals_hip_queue_size(const cals_hip_engine *e);
 int cals_hip_synchronize(cals_hip_engine *e);
 
+/* ---- kernel-level entry point ---- */
+/* mttkrp::mttkrp(X, u, workspace, mode, params) for ONE Ktensor (include/utils/mttkrp.h:77-81,
+ * src/utils/mttkrp.cpp:562-614; what include/experiments/bench_mttkrp_cals.h:49-84 times): the MTTKRP of mode
+ * `mode` from the host factors `factors[n]` (I_n x rank, ld = I_n; factors[mode] is not read) on the engine's
+ * tensor, through the fused MTTKRP kernel + the split reduction, into G_host (I_mode x rank, ld = I_mode).
+ * The engine must be idle (nothing queued or in flight) and rank <= buffer_size; its buffers are left zeroed as
+ * found.  device_ms (may be NULL): time of the MTTKRP kernels on the engine's stream, from a hipEvent pair. */
+int cals_hip_mttkrp(cals_hip_engine *e, int64_t rank, const double *const *factors, int mode, double *G_host,
+                    double *device_ms);
+
 /* ---- inspection (tests) ---- */
 /* MTTKRP of the current multi-factor block for `mode` (mttkrp::mttkrp, src/utils/mttkrp.cpp:562)
  * into G_host (I_mode x active_cols, ld = I_mode) WITHOUT touching the engine state. */

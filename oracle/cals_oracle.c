@@ -446,7 +446,21 @@ static int nnls_any(const uint8_t *active, int64_t n, int value) {
  * OR_NNLS_MAX_EXCHANGES(n) = max(64, 16 n) passes of either loop and reports it (status 2): far above what a
  * terminating row needs (Lawson-Hanson implementations commonly allow 3 n), so that a cycling row cannot hang a
  * test or, on the device, hold a whole launch for thousands of solves. */
-#define OR_NNLS_MAX_EXCHANGES (n > 4 ? 16 * n : 64)
+#define OR_NNLS_DEFAULT_BOUND(n) ((n) > 4 ? 16 * (n) : 64)
+/* Test knobs (tests/test_oracle_nnls_termination.py pins the termination rule on the oracle alone): a bound
+ * override (0 = the default max(64, 16 n)), the cycle rule on / off, and the largest pass count any loop of
+ * the last call reached.  With the bound lifted and the cycle rule off the function IS the reference's
+ * unbounded loop on every input on which that loop ends before the lifted bound. */
+static int64_t or_nnls_bound_override = 0;
+static int or_nnls_cycle_rule = 1;
+static int64_t or_nnls_max_passes = 0;
+void or_nnls_set_termination(int64_t bound, int cycle_rule) {
+  or_nnls_bound_override = bound;
+  or_nnls_cycle_rule = cycle_rule;
+}
+int64_t or_nnls_last_max_passes(void) { return or_nnls_max_passes; }
+#define OR_NNLS_MAX_EXCHANGES (or_nnls_bound_override > 0 ? or_nnls_bound_override : OR_NNLS_DEFAULT_BOUND(n))
+#define OR_NNLS_COUNT(g) do { if ((g) > or_nnls_max_passes) or_nnls_max_passes = (g); } while (0)
 
 /* panel: rows x r (ld) holding the MTTKRP result, overwritten with the constrained solution;
  * H: r x r (ld r) Hadamard product of the other Gramians (NOT destroyed, unlike the unconstrained
@@ -468,6 +482,7 @@ int or_update_factor_nnls(double *panel, int64_t rows, int64_t r, int64_t ld, co
   double *d = y + n, *w = d + n, *s = w + n, *sp = s + n, *Gp = sp + n;
   uint8_t *top = (uint8_t *)xmalloc((size_t)n);
   int status = 0;
+  or_nnls_max_passes = 0;
   for (int64_t i = 0; i < n; i++) sp[i] = 0.0;
   for (int64_t row = 0; row < rows; row++) {
     uint8_t *active = active_all + row * n;
@@ -493,6 +508,7 @@ int or_update_factor_nnls(double *panel, int64_t rows, int64_t r, int64_t ld, co
           np = nnls_calculate_sp(y, sp, H, Gp, active, n);
           if (np < 0) { failed = 1; break; }
           nnls_scatter(d, sp, active, n);
+          OR_NNLS_COUNT(guard + 1);
           if (++guard > OR_NNLS_MAX_EXCHANGES) { status |= 2; break; }
         }
       }
@@ -526,6 +542,7 @@ int or_update_factor_nnls(double *panel, int64_t rows, int64_t r, int64_t ld, co
         }
         np = nnls_calculate_sp(y, sp, H, Gp, active, n);
         if (np < 0) { status |= 1; break; }
+        OR_NNLS_COUNT(guard2 + 1);
         if (++guard2 > OR_NNLS_MAX_EXCHANGES) { status |= 2; break; }
       }
       if (np < 0) break;
@@ -535,7 +552,8 @@ int or_update_factor_nnls(double *panel, int64_t rows, int64_t r, int64_t ld, co
        * loop) has reproduced its own starting state -- d and w are functions of the set -- so every further
        * pass repeats it: this is where the reference's exchange rule cycles and its loop never ends.  Stop at the
        * first such pass (same state as after any number of them) and report it like the bound. */
-      if (memcmp(top, active, (size_t)n) == 0) { status |= 2; break; }
+      if (or_nnls_cycle_rule && memcmp(top, active, (size_t)n) == 0) { status |= 2; break; }
+      OR_NNLS_COUNT(guard + 1);
       if (++guard > OR_NNLS_MAX_EXCHANGES) { status |= 2; break; }
     }
     for (int64_t i = 0; i < n; i++) panel[row + ld * i] = d[i];
@@ -874,6 +892,8 @@ static void ls_free(ls_t *p) {
 int or_cp_als(const double *X, int n_modes, const int64_t *modes, or_model *model,
               const or_params *prm, or_report *rep) {
   if (n_modes < 3 || n_modes > OR_MAX_MODES) return -1;
+  /* error::compute_error (error.cpp:7-30) is 3-way code: with N > 3 the reference reads past its workspace */
+  if (prm->line_search && prm->line_search_method == OR_LS_ERROR_CHECKING_SERIAL && n_modes > 3) return -1;
   const double t_total = now_s();
   int64_t n_el = 1;
   for (int n = 0; n < n_modes; n++) n_el *= modes[n];
@@ -1126,6 +1146,8 @@ static void mkt_compress(mkt_t *m) {
 int or_cp_cals(const double *X, int n_modes, const int64_t *modes, or_model *models,
                int64_t n_models, const or_params *prm, or_report *rep) {
   if (n_modes < 3 || n_modes > OR_MAX_MODES) return -1;
+  /* error::compute_error (error.cpp:7-30) is 3-way code: with N > 3 the reference reads past its workspace */
+  if (prm->line_search && prm->line_search_method == OR_LS_ERROR_CHECKING_SERIAL && n_modes > 3) return -1;
   for (int64_t i = 0; i < n_models; i++)
     if (models[i].rank > prm->buffer_size || models[i].rank < 1)
       return -2; /* the reference would spin forever; reject instead */

@@ -109,6 +109,10 @@ int or_update_factor_unconstrained(double *panel, int64_t rows, int64_t r, int64
 /* active: rows x r bytes, [row][i], 1 = constraint active; in/out across sweeps */
 int or_update_factor_nnls(double *panel, int64_t rows, int64_t r, int64_t ld, const double *H,
                           uint8_t *active);
+/* test knobs of the NNLS termination rule: bound (0 = default max(64, 16 r)), cycle rule on / off; the largest
+ * number of passes any loop of the last or_update_factor_nnls call made */
+void or_nnls_set_termination(int64_t bound, int cycle_rule);
+int64_t or_nnls_last_max_passes(void);
 void or_normalize_mode(double *panel, int64_t rows, int64_t r, int64_t ld, double *lambda,
                        int64_t iteration);
 void or_normalize_all(double *const *factors, int n_modes, const int64_t *modes, int64_t r,

@@ -190,6 +190,17 @@ def update_factor_nnls(G_panel, H, active=None):
     return P, act, int(st)
 
 
+def nnls_set_termination(bound=0, cycle_rule=True):
+    """Test knobs of or_update_factor_nnls: bound = 0 -> the default max(64, 16 r); cycle_rule off + a lifted
+    bound = the reference's unbounded loops (src/utils/update.cpp:95-165) wherever those end."""
+    lib().or_nnls_set_termination(C.c_int64(int(bound)), C.c_int(1 if cycle_rule else 0))
+
+
+def nnls_last_max_passes():
+    lib().or_nnls_last_max_passes.restype = C.c_int64
+    return int(lib().or_nnls_last_max_passes())
+
+
 def fast_error(X_norm, lam, last_factor, last_G, gram_had):
     F, G, H = fcol(last_factor), fcol(last_G), fcol(gram_had)
     lam = np.ascontiguousarray(lam, dtype=np.float64)

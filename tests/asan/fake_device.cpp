@@ -98,6 +98,7 @@ int mttkrp_pick_mt(int m_tiles) {
   return 0;
 }
 int ttm_max_mt(int dtype) { return dtype == CALS_F32 ? 20 : 10; }
+bool ttm_shape_ok(long long S, long long Mp, int dtype) { return dtype == CALS_F32 || (15 * S + 1) * Mp * 8 < (1ll << 32); }
 
 // numeric kernels: nothing to do on the fake device
 hipError_t mttkrp3_launch(int, int, const MttkrpArgs &, hipStream_t) { return hipSuccess; }

@@ -9,7 +9,9 @@
 //           Tensor view of foreign memory, set_lambda / set_factor, generate_jk_ktensors, one cp_cals over
 //           all replicas, set_jk_fiber / denormalize / normalize, cblas_dgemm + the assignment solver,
 //           Matrix views of single columns, concatenate_ktensors;
-//   part 3: CalsReport::print_header / print_to_file with the timer matrices (experiments_utils.cpp:163-187).
+//   part 3: CalsReport::print_header / print_to_file with the timer matrices (experiments_utils.cpp:163-187);
+//   part 4: the MTTKRP micro-benchmark's pattern (include/experiments/bench_mttkrp_cals.h:49-84): mttkrp::mttkrp on
+//           one Ktensor, its timers / flops, and error::compute_fast_error on matrices the caller holds.
 // Usage: ref_style_caller I-J-K MIN:MAX:COPIES [csv]   (small sizes; exit code 0 = all checks passed)
 #include <iostream>
 #include <random>
@@ -18,6 +20,9 @@
 #include "als.h"
 #include "cals.h"
 #include "timer.h"
+#include "utils/error.h"
+#include "utils/mttkrp.h"
+#include "utils/utils.h"
 #include <rectangular_lsap/rectangular_lsap.h>
 
 using std::cerr;
@@ -209,6 +214,59 @@ int main(int argc, char *argv[]) {
     cals_report.output_file_name = argv[3];
     cals_report.print_header(cals_report.output_file_name);
     cals_report.print_to_file(cals_report.output_file_name);
+  }
+  // ------------------------------------------------------------------ part 4: the MTTKRP micro-benchmark
+  if (modes.size() == 3) {
+    const dim_t rank = 5;
+    auto ktensor = Ktensor(rank, modes);
+    ktensor.randomize();
+    auto before = ktensor;  // the factors the MTTKRP reads
+    vector<cals::Matrix> workspace;
+    workspace.emplace_back(cals::Matrix(modes[0] * modes[1], rank));
+    auto params = cals::mttkrp::MttkrpParams();
+    params.method = cals::mttkrp::MTTKRP_METHOD::MTTKRP;
+    for (dim_t mode = 0; mode < 3; mode++) {
+      auto &G = cals::mttkrp::mttkrp(X, ktensor, workspace, mode, params);
+      bad += check(&G == &ktensor.get_factor(mode), "mttkrp returns the mode's factor");
+      // ground truth by plain loops: G[i_mode, c] = sum X[i,j,k] * prod_{n != mode} F_n[i_n, c]
+      double worst = 0.0, scale = 0.0;
+      const dim_t I = modes[0], J = modes[1], K = modes[2];
+      for (dim_t c = 0; c < rank; c++) {
+        vector<double> g(modes[mode], 0.0);
+        for (dim_t k = 0; k < K; k++)
+          for (dim_t j = 0; j < J; j++)
+            for (dim_t i = 0; i < I; i++) {
+              const dim_t idx[3] = {i, j, k};
+              double w = X[i + I * (j + J * k)];
+              for (dim_t n = 0; n < 3; n++)
+                if (n != mode) w *= before.get_factor(n)(idx[n], c);
+              g[idx[mode]] += w;
+            }
+        for (dim_t m = 0; m < modes[mode]; m++) {
+          worst = std::max(worst, std::fabs(g[m] - G(m, c)));
+          scale = std::max(scale, std::fabs(g[m]));
+        }
+      }
+      bad += check(worst <= 1e-12 * std::max(1.0, scale), "mttkrp::mttkrp equals the plain-loop MTTKRP");
+      bad += check(params.flops == 2ull * X.get_n_elements() * rank, "mttkrp flops");
+      bad += check(params.mttkrp_timers.timers[cals::MttkrpTimers::MT_GEMM].get_time() > 0.0 &&
+                       params.mttkrp_timers.timers[cals::MttkrpTimers::MT_KRP].get_time() == 0.0,
+                   "mttkrp timers");
+      ktensor.get_factor(mode).copy(before.get_factor(mode));  // the next mode reads the original factors
+    }
+    // compute_fast_error on a fitted model equals the engine's own error (fused in the update kernel)
+    auto &fitted = cals_input[0];
+    vector<cals::Matrix> gramians(3);
+    for (dim_t n = 0; n < 3; n++) gramians[n] = cals::Matrix(fitted.get_components(), fitted.get_components());
+    cals::ops::update_gramians(fitted, gramians);
+    auto probe = fitted;
+    auto &G = cals::mttkrp::mttkrp(X, probe, workspace, 2, params);
+    cals::Matrix H(fitted.get_components(), fitted.get_components());
+    std::fill(H.get_data(), H.get_data() + H.get_n_elements(), 1.0);
+    for (dim_t n = 0; n < 3; n++) H.hadamard(gramians[n]);
+    const double fe = cals::error::compute_fast_error(X.norm(), fitted.get_lambda(), fitted.get_factor(2), G, H);
+    const double slow = cals::error::compute_error(X, fitted);
+    bad += check(std::fabs(fe - slow) <= 1e-8 * std::max(1.0, slow), "compute_fast_error equals the reconstruction error");
   }
   cout << (bad ? "ref_style_caller: FAILED" : "ref_style_caller: all checks passed") << endl;
   return bad ? 1 : 0;

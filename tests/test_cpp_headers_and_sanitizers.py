@@ -71,6 +71,22 @@ def test_reference_experiment_harness_compiles_and_links_unmodified(tmp_path, ma
 
 
 @pytest.mark.skipif(not os.path.exists(REF_DRIVER), reason="the reference tree is not present on this machine")
+def test_reference_mttkrp_microbenchmark_compiles_and_links_unmodified(tmp_path):
+    """src/experiments/benchmark_cals_mttkrp.cpp with include/experiments/bench_mttkrp{,_cals,_ctf,_planc}.h and
+    bench_utils.h -- the protocol SURVEY section 8(d) cites (bench_mttkrp_cals.h:49-84) -- against this header
+    set: needs the free function mttkrp::mttkrp(const Tensor &, Ktensor &, vector<Matrix> &, dim_t,
+    MttkrpParams &) as a linkable symbol (here: one fused MTTKRP launch on a leased engine, cals_hip_mttkrp)."""
+    exe = str(tmp_path / "bench_mttkrp")
+    cmd = ["g++", "-std=c++17", "-O0", "-fopenmp", '-DSOURCE_DIR="/tmp"'] + INC + ["-I" + os.path.join(REF, "include"),
+           os.path.join(REF, "src", "experiments", "benchmark_cals_mttkrp.cpp"), "-o", exe,
+           "-L" + os.path.join(ROOT, "cp-cals_amd"), "-lcals", "-lcals_hip", "-Wl,-rpath," + os.path.join(ROOT, "cp-cals_amd")]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    r = subprocess.run([exe, "--help"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and "USAGE" in r.stdout
+
+
+@pytest.mark.skipif(not os.path.exists(REF_DRIVER), reason="the reference tree is not present on this machine")
 def test_reference_mex_argument_parser_compiles_unmodified():
     """matlab/matlab_parsing.cpp (the string-argument parser of the three MEX entry points: update-method,
     mttkrp-method, maxiters, buffer-size, tol, cuda / no-cuda, ls / no-ls, ls-interval, ls-step on CalsParams)

@@ -95,6 +95,29 @@ def test_line_search_and_nnls_on_a_4_way_tensor(cc, oracle, inputs, kw):
     _assert_models_match(gm, om, ro.X_norm ** 2, tol=1e-7)
 
 
+def test_error_checking_line_search_is_refused_beyond_3_way(cc, oracle, inputs):
+    """ls::ERROR_CHECKING_SERIAL + N > 3: error::compute_error (error.cpp:7-30) rebuilds a 3-way tensor and
+    subtracts it from all elements of a 4-way X -- undefined behaviour in the reference.  Engine and oracle both
+    refuse the combination instead of each inventing its own meaning (round 2 had two: 11 vs 4 reverts)."""
+    modes, ranks = [6, 5, 4, 3], [2, 3]
+    X = inputs.tensor(modes, 3)
+    e = cc.Engine(modes, sum(ranks))
+    e.set_tensor(X)
+    with pytest.raises(cc.CalsHipError):
+        e.set_params(cc.default_params(line_search=1, line_search_method=1, line_search_interval=2))
+    e.set_params(cc.default_params(line_search=1, line_search_method=0, line_search_interval=2))   # fine
+    e.close()
+    e3 = cc.Engine(modes[:3], sum(ranks))
+    e3.set_params(cc.default_params(line_search=1, line_search_method=1, line_search_interval=2))   # 3-way: fine
+    e3.close()
+    base = inputs.model_factors(modes, ranks, seed=5)
+    models = [oracle.Model([f.copy() for f in fs], lam.copy()) for fs, lam in base]
+    p = oracle.default_params(max_iterations=4, force_max_iter=1, buffer_size=sum(ranks), line_search=1,
+                              line_search_method=1, line_search_interval=2)
+    with pytest.raises(Exception):
+        oracle.cp_cals(X, modes, models, p)
+
+
 def test_queue_jackknife_and_fp32_on_a_5_way_tensor(cc, oracle, inputs):
     modes = [6, 5, 4, 5, 3]
     ranks = [3, 1, 4, 2, 5, 2, 3, 1, 4, 2]

@@ -62,6 +62,50 @@ def test_mttkrp_every_mode_vs_oracle(cc, oracle, inputs, modes, ranks):
     e.close()
 
 
+@pytest.mark.parametrize("modes,rank,dtype", [([20, 20, 20], 5, "f64"), ([13, 12, 11], 33, "f64"),
+                                              ([40, 30, 20], 300, "f64"), ([6, 5, 4, 3], 4, "f64"),
+                                              ([29, 31, 11], 7, "f32")])
+def test_kernel_level_mttkrp_of_one_ktensor_vs_oracle(cc, oracle, inputs, modes, rank, dtype):
+    """cals_hip_mttkrp = mttkrp::mttkrp(X, u, workspace, mode, params) (src/utils/mttkrp.cpp:562-614) for one
+    Ktensor on an idle engine: the callable the reference's MTTKRP micro-benchmark times.  The engine's buffers
+    are left as found (a run right after it equals a run on a fresh engine), rank above the per-model cap of
+    the update kernels is fine (no update runs), a busy engine refuses."""
+    X = inputs.tensor(modes, 2)
+    rng = np.random.default_rng(5)
+    facs = [np.asfortranarray(rng.uniform(-1, 1, (I, rank))) for I in modes]
+    e = cc.Engine(modes, rank, dtype=dtype)
+    e.set_tensor(X)
+    for n in range(len(modes)):
+        G, ms = e.mttkrp(facs, n)
+        assert ms > 0.0
+        want = oracle.mttkrp(X, modes, facs, n, oracle.MTTKRP)
+        assert rel(G, want) < (TOL_KERNEL if dtype == "f64" else 2e-5)
+    for n in range(len(modes)):
+        assert not e.debug_factor(n).any() if e.active_cols else True
+    if rank <= 64 and dtype == "f64":
+        ranks = [rank]
+        base = make_models(inputs, modes, ranks, seed=3)
+        runs = []
+        for eng in (e, cc.Engine(modes, rank)):
+            if eng is not e:
+                eng.set_tensor(X)
+            eng.set_params(cc.default_params(max_iterations=4, force_max_iter=1))
+            m = cc.Model([f.copy() for f in base[0][0]], base[0][1].copy())
+            eng.enqueue(m)
+            eng.run()
+            runs.append(m)
+            if eng is not e:
+                eng.close()
+        for a, b in zip(runs[0].factors, runs[1].factors):
+            assert np.array_equal(a, b)
+        m2 = cc.Model([f.copy() for f in base[0][0]], base[0][1].copy())
+        e.enqueue(m2)
+        e.admit()
+        with pytest.raises(cc.CalsHipError):
+            e.mttkrp(facs, 0)
+    e.close()
+
+
 def test_mttkrp_golden(cc, inputs):
     gold = np.load(os.path.join(GOLD, "mttkrp.npz"))
     for modes, ranks in (([7, 5, 3], [1, 2, 3]), ([3, 3, 3, 3], [7, 2]), ([40, 30, 20], [20] * 7)):

@@ -84,7 +84,16 @@ def _queue_worker(rank, world, port, q):
         got += ks
         time.sleep(rnd.random() * 0.002 * (1 + 3 * rank))  # rank 1 is the slow one
     dist.barrier()
-    q.put((rank, got))
+    # a second queue with the default name in the same job starts at 0 again (own key prefix per instance)
+    wq2 = multi_gpu.WorkQueue(9)
+    got2 = []
+    while True:
+        ks = wq2.claim(2)
+        if not ks:
+            break
+        got2 += ks
+    dist.barrier()
+    q.put((rank, got, got2))
     dist.destroy_process_group()
 
 
@@ -98,9 +107,30 @@ def test_work_queue_hands_out_every_index_once_world2():
     procs = [ctx.Process(target=_queue_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = dict(q.get(timeout=120) for _ in range(world))
+    got = [q.get(timeout=120) for _ in range(world)]
+    res = {r: a for r, a, _ in got}
+    res2 = {r: b for r, _, b in got}
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
     assert sorted(res[0] + res[1]) == list(range(57))
     assert len(res[0]) > len(res[1])
+    assert sorted(res2[0] + res2[1]) == list(range(9))
+
+
+def test_bench_starts_its_own_ranks_when_no_launcher_is_around():
+    """`python bench.py --gpus 2` with WORLD_SIZE unset: the parent (which has made no GPU call) starts the
+    torch.distributed launcher as a child; here, without a GPU, BOTH ranks must reach the "needs a GPU" exit of
+    bench.py and the parent must return the launcher's non-zero status -- not a usage message.  On a GPU box the
+    same path goes on into the process group and the engines."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["HIP_VISIBLE_DEVICES"] = ""        # also on a GPU box: this test exercises the launch, not the engines
+    env["CUDA_VISIBLE_DEVICES"] = ""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo",
+                        "--force-device0", "--steps", "1", "--warmup", "0"], env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode != 0
+    assert "launch with" not in (r.stdout + r.stderr)
+    assert (r.stdout + r.stderr).count("bench.py needs a GPU") >= 1
+    assert "nproc-per-node" not in r.stdout          # nothing but rank 0's JSON line ever goes to stdout
