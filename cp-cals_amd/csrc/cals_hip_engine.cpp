@@ -64,6 +64,8 @@ struct TreePlan {
   PairCfg pair[3];
   void *Tbuf = nullptr;  // T[c][s][m]: buffer x max(S x Mp) elements
   void *Pt = nullptr;    // packed factor of mode a: [NB][Ap][CALS_BN]
+  int pt_mode = -1;      // the mode whose CURRENT factor stands packed in Pt (written by its update launch or by
+  int pt_Ap = 0;         // pack_pt_kernel) with pad height pt_Ap; -1: none -- see pt_invalidate
   int t_second = -1;     // T currently holds the TTM whose `second` is this mode (-1: none) ...
   int t_first = -1;      // ... computed as pair[t_first]
   int *d_changed = nullptr;  // ls_kernel adds the rank of every model whose factors it rewrote
@@ -644,11 +646,13 @@ int launch_ttm(cals_hip_engine *e, int first, int64_t R, Geo *geo_out) {
   const int second = (first + 1) % 3, am = (first + 2) % 3;
   const ModeLayout &L = e->lay[first];
   const Geo g = tree_geometry(e, first, R);
-  {
+  if (tp.pt_mode != am || tp.pt_Ap != L.Ap) {  // not left behind by mode am's update launch (sweep_once)
     const int pk = prof_begin(e, 2, 0, LOG_TTM);
     HIPCHK(pack_pt_launch(e->factor[am], e->modes[am], L.A, L.Ap, g.NB, (int)R, tp.Pt, e->dtype,
                           e->stream));
     prof_end(e, pk);
+    tp.pt_mode = am;
+    tp.pt_Ap = L.Ap;
   }
   TtmArgs a{};
   a.Xp = L.Xp;
@@ -704,6 +708,10 @@ void tree_invalidate(cals_hip_engine *e) {
   e->tree.t_second = e->tree.t_first = -1;
   e->tree.n_stale = 0;
 }
+
+// Something other than an update launch wrote factor columns (admission, eviction, compress, a line-search step,
+// a one-shot MTTKRP, rebind): the packed copy Pt no longer mirrors its mode's factor -- the next TTM packs again.
+void pt_invalidate(cals_hip_engine *e) { e->tree.pt_mode = -1; }
 
 // A line-search step rewrote `changed` columns (0: none) while a T is pending across the sweep boundary.
 // Few of them: keep T, the consumer recomputes just those columns (patch_stale_columns).  Many (the
@@ -814,8 +822,10 @@ int sweep_once(cals_hip_engine *e, bool evict_enabled, bool defer_changed = fals
   int rank_max = 1;  // sizes the update kernel's LDS panel
   size_t n_huge = 0;  // models above CALS_RMAX: the update needs a global H / L block each
   unsigned rank_classes = 0;  // which LDS size classes of the NNLS kernel are in flight
+  int upd_classes = 0;        // update kernels to launch: bit 0 = ranks <= CALS_RFAST, bit 1 = above
   for (auto t : e->registry) {
     rank_max = std::max(rank_max, (int)e->models[t].rank);
+    upd_classes |= (e->models[t].rank <= CALS_RFAST) ? 1 : 2;
     if (e->models[t].rank > CALS_RMAX) n_huge++;
     rank_classes |= 1u << nnls_rank_class((int)e->models[t].rank);
   }
@@ -900,9 +910,40 @@ int sweep_once(cals_hip_engine *e, bool evict_enabled, bool defer_changed = fals
     u.hcounter = e->d_hcounter;
     if (n_huge) HIPCHK(hipMemsetAsync(e->d_hcounter, 0, sizeof(int), e->stream));
     const int pk = prof_begin(e, 1, 0, LOG_UPDATE);
-    if (!g_in_place)
+    // The update bodies for ranks <= CALS_RFAST sum the split-K partial tiles of their model's columns themselves
+    // (UpdateArgs::partial): no reduce launch, no round trip of G through the factor buffer.  The NNLS kernel and
+    // the blocked bodies of larger ranks read G from the factor buffer: reduce first, as before.
+    // Worth it only for small teams: a body sums the pT tiles of a row serially, the reduce kernel spreads them over
+    // the whole chip (C2, pT = 51: 4300 it/s folded against 5870; C3, pT = 12: equal; C4, pT = 6: +0.7 %).
+    static const int fold_max_t = getenv("CALS_UPDATE_FOLD_MAX_T") ? atoi(getenv("CALS_UPDATE_FOLD_MAX_T")) : 8;
+    static const bool no_pack = getenv("CALS_UPDATE_NO_PACK") != nullptr;  // A/B switch
+    const bool fold = !g_in_place && e->prm.update_method == 0 && !(upd_classes & 2) && g.T <= fold_max_t;
+    if (fold) {
+      u.partial = e->partial;
+      u.pT = g.T;
+      u.ldPart = e->lay[n].ldPart;
+    } else if (!g_in_place) {
       HIPCHK(reduce_partials_launch(e->partial, g.T, e->lay[n].ldPart, (int)e->modes[n], (int)R,
                                     e->factor[n], e->dtype, e->stream));
+    }
+    // ... and leave the packed B-operand tiles of the next TTM behind (UpdateArgs::pt) when the NEXT mode's MTTKRP
+    // is a TTM whose inner mode is this one -- i.e. no T is pending for it (sweep order 0 1 2 0 1 2 ...).  A line
+    // search between this sweep's last mode and the next sweep's mode 0 rewrites factors: pt_invalidate below.
+    bool packs = false;
+    if (e->tree.on && e->n_modes == 3 && !(upd_classes & 2) && !no_pack) {
+      const int nxt = (n + 1) % 3;
+      if (e->tree.pair[nxt].on && e->tree.t_second != nxt) {
+        u.pt = e->tree.Pt;
+        u.ptAp = e->lay[nxt].Ap;
+        packs = true;
+      }
+    }
+    if (packs) {
+      e->tree.pt_mode = n;
+      e->tree.pt_Ap = u.ptAp;
+    } else if (e->tree.pt_mode == n) {
+      pt_invalidate(e);  // factor n is being rewritten and Pt keeps its old columns
+    }
     if (e->prm.update_method == 1) {  // update::NNLS (cals.cpp:244-248)
       NnlsArgs q{};
       q.slots = e->d_slots;
@@ -926,7 +967,7 @@ int sweep_once(cals_hip_engine *e, bool evict_enabled, bool defer_changed = fals
       if (n_huge) HIPCHK(hipMemsetAsync(e->d_hcounter, 0, sizeof(int), e->stream));
       u.rowdot = e->rowdot;
     }
-    HIPCHK(update_launch(u, rank_max, e->stream));
+    HIPCHK(update_launch(u, rank_max, e->stream, upd_classes));
     prof_end(e, pk);
   }
   e->cur_mode = -1;
@@ -934,6 +975,7 @@ int sweep_once(cals_hip_engine *e, bool evict_enabled, bool defer_changed = fals
     LsArgs la = make_ls_args(e);
     const int pk = prof_begin(e, 2, 0, LOG_LS);
     const bool pending = e->tree.t_second >= 0;  // a T shared across the sweep boundary
+    pt_invalidate(e);  // the line-search kernels may rewrite any model's factors
     if (pending) HIPCHK(hipMemsetAsync(e->tree.d_changed, 0, sizeof(int), e->stream));
     la.changed = pending ? e->tree.d_changed : nullptr;
     if (e->prm.line_search_method == 0) {
@@ -1159,6 +1201,7 @@ int remove_models(cals_hip_engine *e, std::vector<int64_t> rm) {
   }
   e->slots_dirty = true;
   tree_invalidate(e);
+  pt_invalidate(e);
   adjust_edges(e);
   return CALS_HIP_OK;
 }
@@ -1172,6 +1215,7 @@ int compress(cals_hip_engine *e) {
     return CALS_HIP_OK;
   }
   tree_invalidate(e);
+  pt_invalidate(e);
   // host bookkeeping request by request (as the reference applies them, left to right); the column
   // traffic of ALL requests and ALL buffers then goes out as one gather + one scatter launch
   std::vector<int> src, dst, pairs;
@@ -1269,6 +1313,7 @@ int admit(cals_hip_engine *e, int64_t *n_admitted) {
   if (!admitted.empty()) {
     e->slots_dirty = true;
     tree_invalidate(e);
+    pt_invalidate(e);
     // Ktensor::attach: copy the models' factors into the buffer columns -- all admitted models at
     // once: packed (rounded to fp32 for an fp32 engine) into pinned host memory, ONE H2D, ONE scatter
     // launch that writes every column of every factor and of lambda to its place.
@@ -1734,6 +1779,7 @@ int cals_hip_rebind(cals_hip_engine *e, int64_t buffer_size) {
   e->nnls_status = 0;
   if (e->d_nnls_status) HIPCHK(hipMemsetAsync(e->d_nnls_status, 0, sizeof(int), e->stream));
   tree_invalidate(e);
+  pt_invalidate(e);
   adjust_edges(e);
   return CALS_HIP_OK;
 }
@@ -2269,6 +2315,7 @@ int cals_hip_mttkrp(cals_hip_engine *e, int64_t rank, const double *const *facto
   if (rank < 1 || rank > e->buffer) return fail(e, CALS_HIP_ERR_ARG, "cals_hip_mttkrp: rank must be in [1, buffer_size]");
   int rc = flush_pending_out(e);
   if (rc) return rc;
+  pt_invalidate(e);
   // the Ktensor's factors into columns [0, rank) of the (all-zero) multi-factor buffers
   std::vector<std::vector<float>> f32((size_t)e->n_modes);
   for (int n = 0; n < e->n_modes; n++) {

@@ -164,8 +164,20 @@ struct UpdateArgs {
   // NNLS update: nnls_launch already replaced the MTTKRP result in `factor` by the constrained
   // solution and left <x_row, g_row> here ([n_slots][I]); the kernel then skips Cholesky + solves
   const double *rowdot;
+  // Split-K partial tiles of the MTTKRP that produced this mode's G ([NB * pT] tiles of ldPart x CALS_BN, element
+  // type = dtype), or nullptr when G already stands in `factor`.  Non-null: the bodies for ranks <= CALS_RFAST sum
+  // a model's columns over the pT tiles themselves (fixed order t = 0 .. pT-1, fp64, rounded to the storage type:
+  // exactly what reduce_partials_kernel writes) -- no reduce launch, no 78 MB round trip at C3.
+  const void *partial;
+  int pT, ldPart;
+  // Packed B-operand tiles of the NEXT dimension-tree TTM whose inner mode is this one (Pt[column block][a][128],
+  // a < ptAp, ttm_kernel.hip) or nullptr: the bodies write their model's columns of the normalised factor there
+  // on their way out -- no pack_pt launch in front of that TTM.
+  void *pt;
+  int ptAp;
 };
-hipError_t update_launch(const UpdateArgs &a, int rmax_needed, hipStream_t st);
+// classes: bit 0 = models of rank <= CALS_RFAST in flight, bit 1 = models above it (0 = unknown: both kernels)
+hipError_t update_launch(const UpdateArgs &a, int rmax_needed, hipStream_t st, int classes = 0);
 
 // update::update_factor_non_negative_constrained for one mode (nnls_kernel.hip)
 struct NnlsArgs {

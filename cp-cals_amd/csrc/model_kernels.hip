@@ -27,6 +27,10 @@ namespace calship {
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 
+// update kernels: one workgroup of 4 waves per model
+#define UPD_THREADS 256
+#define UPD_WAVES 4
+
 #ifdef CALS_DIAG
 #define UPD_STAMP(k)                                                                          \
   do {                                                                                        \
@@ -42,8 +46,80 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 #define UPD_STAMP_H(k) do { } while (0)
 #endif
 
+// The update bodies are non-inlined functions (one per rank class).  Handing them the kernel's by-value
+// UpdateArgs by reference made the compiler copy all 352 bytes of it into every lane's scratch at kernel start
+// and read every field back through scratch; instead every body reads the struct where the dispatcher put it --
+// the calling kernel's kernarg segment (constant address space): every field read is a scalar load, and there is
+// no argument frame.  The kernel hands the segment's address over as an ordinary pointer argument (a VGPR pair under
+// the calling convention; __builtin_amdgcn_kernarg_segment_ptr() itself reads as NULL inside a non-kernel function)
+// and the body makes it wave-uniform again with two v_readfirstlane.
+typedef const __attribute__((address_space(4))) UpdateArgs *UpdArgsPtr;
+typedef const __attribute__((address_space(4))) UpdateArgs &UpdArgsRef;
+__device__ __forceinline__ UpdArgsPtr upd_kernargs() {
+  // kernel side: the kernels below take ONE explicit argument, the UpdateArgs, at offset 0 of the kernarg segment
+  return (UpdArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
+}
+__device__ __forceinline__ UpdArgsRef upd_uniform(UpdArgsPtr p) {
+  const unsigned long long v = (unsigned long long)p;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return *(UpdArgsPtr)(((unsigned long long)hi << 32) | lo);
+}
+
+// One row of a model's G: from the factor buffer (already reduced) or summed here over the split-K partial tiles
+// (UpdateArgs::partial).  Tile loop outermost: the RMAX loads of a step are independent, the sum of every entry
+// runs t = 0 .. pT-1 in order -- reduce_partials_kernel's order and rounding, bit for bit.
+template <int RMAX, typename T>
+__device__ __forceinline__ void upd_load_g_row(UpdArgsRef a, const T *fac, int i, int I, int col, int r,
+                                               double (&x)[RMAX]) {
+  if (a.partial == nullptr) {
+#pragma unroll
+    for (int c = 0; c < RMAX; ++c) x[c] = (c < r) ? (double)fac[i + (long long)I * c] : 0.0;
+    return;
+  }
+  const long long tile = (long long)a.ldPart * CALS_BN;
+  // a model's columns are consecutive; they cross a 128-column block boundary at most once (at local column cs)
+  const int cs = CALS_BN - (col & (CALS_BN - 1));
+  const long long jump = (long long)a.pT * tile - tile;
+  const T *p0 = static_cast<const T *>(a.partial) + (long long)(col >> 7) * a.pT * tile +
+                (long long)a.ldPart * (col & (CALS_BN - 1)) + i;
+#pragma unroll
+  for (int c = 0; c < RMAX; ++c) x[c] = 0.0;
+  for (int t = 0; t < a.pT; ++t) {
+    const T *pt = p0 + (long long)t * tile;
+#pragma unroll
+    for (int c = 0; c < RMAX; ++c)
+      if (c < r) x[c] += (double)pt[(long long)a.ldPart * c + (c >= cs ? jump : 0)];
+  }
+  if constexpr (!std::is_same<T, double>::value) {
+#pragma unroll
+    for (int c = 0; c < RMAX; ++c) x[c] = (double)(T)x[c];
+  }
+}
+
+// Pt[(column block)][a][128] = the model's columns of the normalised factor (rows 0 .. I-1) and zeros in the pad rows
+// I .. ptAp-1 (UpdateArgs::pt): element k of the model's I x r panel is (row k / r, column k % r), so consecutive
+// lanes write consecutive columns of one row -- r * sizeof(T) contiguous bytes -- instead of 64 different rows.
+template <typename T, typename PANEL>
+__device__ __forceinline__ void upd_write_pt(UpdArgsRef a, PANEL panel, long long pld, int I, int col, int r, int tid) {
+  T *const pt = static_cast<T *>(a.pt);
+  const int n = a.ptAp * r;
+  int i = tid / r, c = tid - i * r;
+  const int di = UPD_THREADS / r, dc = UPD_THREADS - di * r;
+  for (int k = tid; k < n; k += UPD_THREADS) {
+    const int gc = col + c;
+    const T v = (i < I) ? (T)panel[i + pld * c] : (T)0;
+    pt[((long long)(gc >> 7) * a.ptAp + i) * CALS_BN + (gc & (CALS_BN - 1))] = v;
+    i += di;
+    c += dc;
+    if (c >= r) {
+      c -= r;
+      ++i;
+    }
+  }
+}
+
 // finish_kernel's rule for one model (see UpdateArgs::fin)
-__device__ __forceinline__ void apply_finish_rule(const UpdateArgs &a, int slot) {
+__device__ __forceinline__ void apply_finish_rule(UpdArgsRef a, int slot) {
   const long long it = a.mt.iters[slot];
   bool evict = false;
   if (a.fin.evict_enabled) {
@@ -171,24 +247,35 @@ __device__ __forceinline__ void gramian_rows(PTR panel, int row0, int row1, int 
 // ---------------------------------------------------------------------------------------------
 // update: one workgroup of 4 waves per model
 // ---------------------------------------------------------------------------------------------
-#define UPD_THREADS 256
-#define UPD_WAVES 4
 
+// 26.7 KB: the partial Gramian tiles (gp, written after the last barrier-separated use of H / L, 1 / diagonal and
+// the column statistics) share their storage with those -- 39.5 KB as separate fields kept a second workgroup
+// off the CU at C3's shape (48 KB panel).  update_body_huge also borrows gp[0] for its 16 x 17 diagonal block
+// while it factors (it keeps H / L elsewhere and reads dinv, which lies behind that block).
 struct UpdShared {
-  double Hs[CALS_RFAST * CALS_RFAST];
-  double dinv[CALS_GLD];
+  union {
+    struct {
+      double Hs[CALS_RFAST * CALS_RFAST];
+      double dinv[CALS_GLD];
+      double red[UPD_WAVES][CALS_RFAST][2];
+      int redi[UPD_WAVES][CALS_RFAST];
+    };
+    double gp[UPD_WAVES][3][256];
+  };
   double lams[CALS_GLD];
-  double red[UPD_WAVES][CALS_RFAST][2];
-  int redi[UPD_WAVES][CALS_RFAST];
   double redt[UPD_WAVES];
-  double gp[UPD_WAVES][3][256];
 };
+static_assert(sizeof(double) * (16 * 17) <= sizeof(double) * CALS_RFAST * CALS_RFAST, "s_dblk must end before dinv");
 
 // noinline: inlining all rank classes into one kernel made the register allocator spill heavily
-// (each body alone fits); as separate functions each gets its own allocation.
+// (each body alone fits); as separate functions each gets its own allocation.  noreturn: a body is the last thing
+// its kernel does, so it ends the wave itself (s_endpgm) -- a returning function would first reload the
+// callee-saved registers it saved on entry (47 scratch loads + a wait at rank 20) for a caller that ends at once.
+#define UPD_BODY_ATTR __attribute__((noinline, noreturn))
 template <int RMAX, typename T>
-__device__ __attribute__((noinline)) void update_body(const UpdateArgs &a, int slot, int r,
+static __device__ UPD_BODY_ATTR void update_body(UpdArgsPtr a_ptr, int slot, int r,
                                                       UpdShared &sh) {
+  UpdArgsRef a = upd_uniform(a_ptr);  // the calling kernel's argument block (constant memory, scalar loads)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int col = a.mt.col[slot];
   const long long iters = a.mt.iters[slot];
@@ -271,11 +358,9 @@ __device__ __attribute__((noinline)) void update_body(const UpdateArgs &a, int s
     asm volatile("" ::: "memory");
     // G row: the MTTKRP result, already reduced over the split partials into the factor buffer
     // (the reference's MTTKRP overwrites factor n too, src/utils/mttkrp.cpp:311)
+    upd_load_g_row<RMAX, T>(a, fac, i, I, col, r, x);
 #pragma unroll
-    for (int c = 0; c < RMAX; ++c) {
-      x[c] = (c < r) ? (double)fac[i + (long long)I * c] : 0.0;
-      g[c] = x[c];
-    }
+    for (int c = 0; c < RMAX; ++c) g[c] = x[c];
     if (!solved) {
       // B := B * inv(L^T)   (dtrsm Right, Lower, Trans)
 #pragma unroll
@@ -399,6 +484,7 @@ __device__ __attribute__((noinline)) void update_body(const UpdateArgs &a, int s
     }
   }
   __syncthreads();
+  if (a.pt) upd_write_pt<T>(a, (const T *)fac, (long long)I, I, col, r, tid);
 
   UPD_STAMP(6);
   // update_gramian: rows split over the four waves, partial tiles combined in fixed order
@@ -466,6 +552,7 @@ __device__ __attribute__((noinline)) void update_body(const UpdateArgs &a, int s
       if (a.fin.on) apply_finish_rule(a, slot);
     }
   }
+  __builtin_amdgcn_endpgm();  // the body ends the wave (see UPD_BODY_ATTR): no epilogue that reloads callee-saved registers
 }
 
 // The same update with the model's factor panel kept in LDS between the phases (used when
@@ -481,8 +568,9 @@ __device__ __attribute__((noinline)) void update_body(const UpdateArgs &a, int s
 extern __shared__ __attribute__((aligned(16))) unsigned char upd_dyn[];
 
 template <int RMAX, typename T>
-__device__ __attribute__((noinline)) void update_body_lds(const UpdateArgs &a, int slot, int r,
+static __device__ UPD_BODY_ATTR void update_body_lds(UpdArgsPtr a_ptr, int slot, int r,
                                                           UpdShared &sh) {
+  UpdArgsRef a = upd_uniform(a_ptr);  // the calling kernel's argument block (constant memory, scalar loads)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int col = a.mt.col[slot];
   const long long iters = a.mt.iters[slot];
@@ -587,11 +675,9 @@ __device__ __attribute__((noinline)) void update_body_lds(const UpdateArgs &a, i
   for (int i = tid; i < I; i += UPD_THREADS) {
     double x[RMAX], g[RMAX];
     asm volatile("" ::: "memory");  // keep L in LDS (see update_body)
+    upd_load_g_row<RMAX, T>(a, fac, i, I, col, r, x);
 #pragma unroll
-    for (int c = 0; c < RMAX; ++c) {
-      x[c] = (c < r) ? (double)fac[i + (long long)I * c] : 0.0;
-      g[c] = x[c];
-    }
+    for (int c = 0; c < RMAX; ++c) g[c] = x[c];
     if (!solved) {
 #pragma unroll
       for (int k = 0; k < RMAX; ++k) {
@@ -717,6 +803,7 @@ __device__ __attribute__((noinline)) void update_body_lds(const UpdateArgs &a, i
     }
   }
   __syncthreads();
+  if (a.pt) upd_write_pt<T>(a, (const T *)xs, (long long)xld, I, col, r, tid);
   UPD_STAMP(6);
 
   // update_gramian: rows split over the four waves, partial tiles combined in fixed order
@@ -784,6 +871,7 @@ __device__ __attribute__((noinline)) void update_body_lds(const UpdateArgs &a, i
       if (a.fin.on) apply_finish_rule(a, slot);
     }
   }
+  __builtin_amdgcn_endpgm();  // the body ends the wave (see UPD_BODY_ATTR): no epilogue that reloads callee-saved registers
 }
 
 __device__ __forceinline__ double lane_bcast(double v, int l) {  // l wave-uniform
@@ -840,8 +928,9 @@ __device__ __forceinline__ v4d gramian_tile_b8(PTR panel, int row0, int row1, lo
 // reads and exec-mask guards per thread, 0.7 ms per launch at rank 64 -- slower than this code through L2.)
 #define UPD_HLDS_LD 66
 template <typename T, bool HLDS>
-__device__ __attribute__((noinline)) void update_body_huge(const UpdateArgs &a, int slot, int r,
+static __device__ UPD_BODY_ATTR void update_body_huge(UpdArgsPtr a_ptr, int slot, int r,
                                                            UpdShared &sh) {
+  UpdArgsRef a = upd_uniform(a_ptr);  // the calling kernel's argument block (constant memory, scalar loads)
   constexpr int LD = HLDS ? UPD_HLDS_LD : CALS_GLD;
   constexpr int XB = 16;
   typedef double v2d __attribute__((ext_vector_type(2)));
@@ -1268,53 +1357,74 @@ __device__ __attribute__((noinline)) void update_body_huge(const UpdateArgs &a, 
       if (a.fin.on) apply_finish_rule(a, slot);
     }
   }
+  __builtin_amdgcn_endpgm();  // the body ends the wave (see UPD_BODY_ATTR): no epilogue that reloads callee-saved registers
 }
 
+// Three kernels, one per body class, each launched only when its class is in flight (update_launch); the
+// workgroups of the other classes' models return at once.  One kernel dispatching to all sixteen bodies gave every
+// rank-1..20 model the register budget and call-frame scratch of the rank-33..256 body (458 unified registers,
+// 484 B of scratch per lane: one workgroup per CU).
+//   update_lds_kernel   ranks <= 32, the panel LDS resident: __launch_bounds__(256, 2) = at most 256 registers, so
+//                       two workgroups share a CU wherever the LDS allows it (C4: 512 models on 256 CUs)
+//   update_hbm_kernel   ranks <= 32, modes too tall for LDS: the bodies that go through HBM between the passes
+//   update_huge_kernel  ranks 33..256
+#define UPD_DISPATCH(BODY)                      \
+  do {                                          \
+    if (r <= 4)                                 \
+      BODY<4, T>(a_ptr, slot, r, sh);               \
+    else if (r <= 8)                            \
+      BODY<8, T>(a_ptr, slot, r, sh);               \
+    else if (r <= 12)                           \
+      BODY<12, T>(a_ptr, slot, r, sh);              \
+    else if (r <= 16)                           \
+      BODY<16, T>(a_ptr, slot, r, sh);              \
+    else if (r <= 20)                           \
+      BODY<20, T>(a_ptr, slot, r, sh);              \
+    else if (r <= 24)                           \
+      BODY<24, T>(a_ptr, slot, r, sh);              \
+    else                                        \
+      BODY<32, T>(a_ptr, slot, r, sh);              \
+  } while (0)
+
 template <typename T>
-__global__ void __launch_bounds__(UPD_THREADS, 1) update_kernel(const UpdateArgs a) {
+__global__ void __launch_bounds__(UPD_THREADS, 2) update_lds_kernel(const UpdateArgs a_by_value) {
+  (void)a_by_value;
+  UpdArgsPtr a_ptr = upd_kernargs();
+  UpdArgsRef a = *a_ptr;
   __shared__ UpdShared sh;
   const int slot = a.slots[blockIdx.x];
   const int r = a.mt.rank[slot];
-  if (r > CALS_RMAX) {
-    update_body_huge<T, false>(a, slot, r, sh);
-    return;
-  }
-  if (r > CALS_RFAST) {
-    update_body_huge<T, true>(a, slot, r, sh);
-    return;
-  }
-  if (a.xld > 0) {  // the panel fits in LDS next to UpdShared (update_launch decides)
-    if (r <= 4)
-      update_body_lds<4, T>(a, slot, r, sh);
-    else if (r <= 8)
-      update_body_lds<8, T>(a, slot, r, sh);
-    else if (r <= 12)
-      update_body_lds<12, T>(a, slot, r, sh);
-    else if (r <= 16)
-      update_body_lds<16, T>(a, slot, r, sh);
-    else if (r <= 20)
-      update_body_lds<20, T>(a, slot, r, sh);
-    else if (r <= 24)
-      update_body_lds<24, T>(a, slot, r, sh);
-    else
-      update_body_lds<32, T>(a, slot, r, sh);
-    return;
-  }
-  if (r <= 4)
-    update_body<4, T>(a, slot, r, sh);
-  else if (r <= 8)
-    update_body<8, T>(a, slot, r, sh);
-  else if (r <= 12)
-    update_body<12, T>(a, slot, r, sh);
-  else if (r <= 16)
-    update_body<16, T>(a, slot, r, sh);
-  else if (r <= 20)
-    update_body<20, T>(a, slot, r, sh);
-  else if (r <= 24)
-    update_body<24, T>(a, slot, r, sh);
-  else
-    update_body<32, T>(a, slot, r, sh);
+  if (r > CALS_RFAST) return;
+  UPD_DISPATCH(update_body_lds);
 }
+
+template <typename T>
+__global__ void __launch_bounds__(UPD_THREADS, 2) update_hbm_kernel(const UpdateArgs a_by_value) {
+  (void)a_by_value;
+  UpdArgsPtr a_ptr = upd_kernargs();
+  UpdArgsRef a = *a_ptr;
+  __shared__ UpdShared sh;
+  const int slot = a.slots[blockIdx.x];
+  const int r = a.mt.rank[slot];
+  if (r > CALS_RFAST) return;
+  UPD_DISPATCH(update_body);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(UPD_THREADS, 1) update_huge_kernel(const UpdateArgs a_by_value) {
+  (void)a_by_value;
+  UpdArgsPtr a_ptr = upd_kernargs();
+  UpdArgsRef a = *a_ptr;
+  __shared__ UpdShared sh;
+  const int slot = a.slots[blockIdx.x];
+  const int r = a.mt.rank[slot];
+  if (r <= CALS_RFAST) return;
+  if (r > CALS_RMAX)
+    update_body_huge<T, false>(a_ptr, slot, r, sh);
+  else
+    update_body_huge<T, true>(a_ptr, slot, r, sh);
+}
+#undef UPD_DISPATCH
 
 // G[i, c] = sum_t partial[(c / 128) * T + t][i, c % 128], t = 0..T-1 in this fixed order
 // (deterministic split-K reduction of the MTTKRP, summed in fp64), written into the multi-factor
@@ -1451,7 +1561,16 @@ hipError_t init_slots_launch(const int *desc, int n, const ModelTable &mt, hipSt
 }
 
 // rmax_needed: largest rank among the models in flight (sizes the LDS panel)
-hipError_t update_launch(const UpdateArgs &a_in, int rmax_needed, hipStream_t st) {
+template <typename K>
+static hipError_t upd_raise_lds(K kernel, AttrOnce &once, size_t budget) {
+  return once.ensure([&] {
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)budget);
+  });
+}
+
+// rank_small / rank_big: are there models of rank <= CALS_RFAST / above it in flight (both unknown -> both launched)
+hipError_t update_launch(const UpdateArgs &a_in, int rmax_needed, hipStream_t st, int classes) {
   if (a_in.n_slots <= 0) return hipSuccess;
   UpdateArgs a = a_in;
   const size_t es = (a.dtype == CALS_F32) ? sizeof(float) : sizeof(double);
@@ -1461,30 +1580,40 @@ hipError_t update_launch(const UpdateArgs &a_in, int rmax_needed, hipStream_t st
   dyn = (dyn + 15) / 16 * 16;
   const size_t budget = (size_t)160 * 1024 - sizeof(UpdShared) - 1024;
   static const bool no_lds = getenv("CALS_UPDATE_NO_LDS") != nullptr;  // A/B switch
-  // ranks 33..64 in flight: update_body_huge<T, true> keeps H (64 columns, ld 66) + 4 partial tiles in dynamic LDS
-  const size_t big = (rmax_needed > CALS_RFAST) ? (size_t)(UPD_HLDS_LD * CALS_RMAX + UPD_WAVES * 256) * sizeof(double) : 0;
-  if (dyn <= budget && !no_lds) {
-    a.xld = xld;
-  } else {
-    a.xld = 0;
-    dyn = 0;
+  const bool f32 = a.dtype == CALS_F32;
+  const bool small = (classes & 1) != 0 || classes == 0, big = (classes & 2) != 0 || classes == 0;
+  hipError_t e = hipSuccess;
+  if (small) {
+    if (dyn <= budget && !no_lds) {
+      a.xld = xld;
+      static AttrOnce once_f64, once_f32;  // the limit is raised to the whole budget, once per device
+      if (f32) {
+        if ((e = upd_raise_lds(&update_lds_kernel<float>, once_f32, budget)) != hipSuccess) return e;
+        hipLaunchKernelGGL(update_lds_kernel<float>, dim3(a.n_slots), dim3(UPD_THREADS), dyn, st, a);
+      } else {
+        if ((e = upd_raise_lds(&update_lds_kernel<double>, once_f64, budget)) != hipSuccess) return e;
+        hipLaunchKernelGGL(update_lds_kernel<double>, dim3(a.n_slots), dim3(UPD_THREADS), dyn, st, a);
+      }
+    } else {
+      a.xld = 0;
+      if (f32)
+        hipLaunchKernelGGL(update_hbm_kernel<float>, dim3(a.n_slots), dim3(UPD_THREADS), 0, st, a);
+      else
+        hipLaunchKernelGGL(update_hbm_kernel<double>, dim3(a.n_slots), dim3(UPD_THREADS), 0, st, a);
+    }
   }
-  if (big > dyn) dyn = big;  // the two uses of the dynamic region never coexist in one workgroup
-  static AttrOnce once_f64, once_f32;  // the limit is raised to the whole budget, once per device
-  if (a.dtype == CALS_F32) {
-    const hipError_t e = once_f32.ensure([&] {
-      return hipFuncSetAttribute(reinterpret_cast<const void *>(&update_kernel<float>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)budget);
-    });
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(update_kernel<float>, dim3(a.n_slots), dim3(UPD_THREADS), dyn, st, a);
-  } else {
-    const hipError_t e = once_f64.ensure([&] {
-      return hipFuncSetAttribute(reinterpret_cast<const void *>(&update_kernel<double>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)budget);
-    });
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(update_kernel<double>, dim3(a.n_slots), dim3(UPD_THREADS), dyn, st, a);
+  if (big && (rmax_needed > CALS_RFAST || classes == 0)) {
+    // ranks 33..64: update_body_huge<T, true> keeps H (64 columns, ld 66) + 4 partial tiles in dynamic LDS
+    const size_t hdyn = (size_t)(UPD_HLDS_LD * CALS_RMAX + UPD_WAVES * 256) * sizeof(double);
+    a.xld = 0;
+    static AttrOnce once_f64, once_f32;
+    if (f32) {
+      if ((e = upd_raise_lds(&update_huge_kernel<float>, once_f32, budget)) != hipSuccess) return e;
+      hipLaunchKernelGGL(update_huge_kernel<float>, dim3(a.n_slots), dim3(UPD_THREADS), hdyn, st, a);
+    } else {
+      if ((e = upd_raise_lds(&update_huge_kernel<double>, once_f64, budget)) != hipSuccess) return e;
+      hipLaunchKernelGGL(update_huge_kernel<double>, dim3(a.n_slots), dim3(UPD_THREADS), hdyn, st, a);
+    }
   }
   return hipGetLastError();
 }

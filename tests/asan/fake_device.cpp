@@ -113,7 +113,7 @@ hipError_t group_contract_launch(const GroupContractArgs &, hipStream_t) { retur
 hipError_t finish_launch(const FinishArgs &a, hipStream_t);
 // the numeric part is a no-op; the end-of-sweep rule the real launch applies for the last mode (UpdateArgs::fin)
 // is the fake finish rule below
-hipError_t update_launch(const UpdateArgs &a, int, hipStream_t st) {
+hipError_t update_launch(const UpdateArgs &a, int, hipStream_t st, int) {
   if (!a.fin.on) return hipSuccess;
   FinishArgs f{};
   f.slots = a.slots;
