@@ -4,7 +4,7 @@
 // MI355X engine (include/cals_hip.h, libcals_hip.so).  A caller written against the reference's headers
 // (`#include "cals.h"`, "als.h", "timer.h", "ktensor.h", ...) compiles against this directory unchanged:
 //     g++ -std=c++17 -I cp-cals_amd/cals -I cp-cals_amd/cals/utils caller.cpp -L cp-cals_amd -lcals -lcals_hip
-// (tests/test_reference_driver_compat.py does exactly that with the reference's own src/examples/driver.cpp).
+// (tests/test_cpp_headers_and_sanitizers.py does exactly that with the reference's own src/examples/driver.cpp).
 #ifndef CALS_AMD_CALS_H
 #define CALS_AMD_CALS_H
 

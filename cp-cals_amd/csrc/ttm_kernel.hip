@@ -33,6 +33,32 @@
 
 namespace calship {
 
+#ifndef CALS_TTM_RING
+#define CALS_TTM_RING 6
+#endif
+#ifndef CALS_TTM_ROLL
+#define CALS_TTM_ROLL 1  // fp64: rolling T flush inside the first stage of the next s (see TtmBody)
+#endif
+// Timing-only stripping, compile time (results garbage; tools/ttm_strip.sh builds the variants): bit 1 no T stores,
+// 8 no P DMA, 16 no X DMA, 32 no flush FMAs, 64 no Q reads, 128 no stage barrier, 256 P operands read once,
+// 512 no vmcnt wait in front of the barrier.  (The run-time CALS_TTM_DBG bits of CALS_DIAG builds cost registers:
+// the DIAG kernel spills and runs at half speed -- useless for this.)
+#ifndef CALS_TTM_STRIP
+#define CALS_TTM_STRIP 0
+#endif
+// Which waves issue a stage's LDS-DMA: 8 = all of them (a piece every 8th wave), 4 = waves 4-7 only (the group that
+// takes its barrier at the stage start; waves 0-3 then carry no DMA instruction and no vmcnt wait at all)
+#ifndef CALS_TTM_DMAW
+#define CALS_TTM_DMAW 8
+#endif
+// 1: Q[s, :] fetched and read only in the stage of the last a-block of s (the one flush that consumes it) instead
+// of in every stage.  One DMA instruction and four LDS reads less per stage, but the wave-uniform branches that
+// select it cost more: measured 2.30 ms against 2.274 ms per launch at C3 -- off.
+#ifndef CALS_TTM_QLAST
+#define CALS_TTM_QLAST 0
+#endif
+#define STRIP(bit) ((CALS_TTM_STRIP & (bit)) != 0)
+
 template <int MT, typename T>
 struct TtmCfg {
   static constexpr int ES = (int)sizeof(T);
@@ -40,7 +66,8 @@ struct TtmCfg {
   static constexpr int SLAB = 16 * LDL;              // X slab: 16 a-rows x LDL
   static constexpr int PE = 1024 / ES;               // elements per 1-KiB DMA piece
   static constexpr int PIECES = SLAB / PE;
-  static constexpr int NP = (PIECES + 7) / 8;        // X pieces per wave (upper bound)
+  static constexpr int DW = (ES == 8) ? CALS_TTM_DMAW : 8;  // DMA-issuing waves (fp64 experiment; fp32: all)
+  static constexpr int NP = (PIECES + DW - 1) / DW;  // X pieces per issuing wave (upper bound)
   static constexpr int QOFF = SLAB;                  // the stage's 128 Q values
   static constexpr int QPE = 256 / ES;               // Q elements per 4-byte-per-lane DMA piece
   static constexpr int QPIECES = CALS_BN / QPE;      // 4 (f64) or 2 (f32)
@@ -49,19 +76,13 @@ struct TtmCfg {
   static constexpr int PLB = (ES == 8) ? 16 : 4;     // bytes per lane of one P DMA instruction
   static constexpr int PPE = 64 * PLB / ES;          // elements per P DMA instruction: 128 | 64
   static constexpr int PPR = CALS_BN / PPE;          // instructions per P row: 1 | 2
-  static constexpr int NPP = 16 * PPR / 8;           // P instructions per wave: 2 | 4
+  static constexpr int NPP = 16 * PPR / DW;          // P instructions per issuing wave: 2 | 4 (DW = 8)
   static constexpr int BUF = POFF + 16 * PP;
   static constexpr int SP = 144 / ES;                // staging tile pitch: 18 f64 | 36 f32 per column
   static constexpr int STG = 16 * SP;                // per-wave staging tile (T flush transpose)
   static constexpr int LDS_BYTES = (3 * BUF + (ES == 4 ? 8 * STG : 0)) * ES;  // staging: fp32 only
   static constexpr int NQ = (ES == 8) ? 4 : 1;       // Q values a lane needs per s (see TtmBody)
   static constexpr int N = 4 * MT;                   // MFMAs per slab per wave
-#ifndef CALS_TTM_RING
-#define CALS_TTM_RING 6
-#endif
-#ifndef CALS_TTM_ROLL
-#define CALS_TTM_ROLL 1  // fp64: rolling T flush inside the first stage of the next s (see TtmBody)
-#endif
   static constexpr int RING = (ES == 4) ? 8 : CALS_TTM_RING;
   static constexpr int D = N < RING ? N : RING;      // operand ring depth
   static constexpr int H = N / 2;                    // barrier position
@@ -77,9 +98,16 @@ struct TtmPipe {
   // flush reads the stage's Q values mid-stream)
   template <int I, int EXTRA = 0>
   static __device__ __forceinline__ void step(acc_t (&acc)[MT], T (&ring)[C::D], const T (&bq)[4],
-                                              unsigned base) {
-    constexpr int outstanding = ((C::D - 1 < C::N - 1 - I) ? C::D - 1 : C::N - 1 - I) + EXTRA;
-    asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(outstanding));
+                                              unsigned base, bool extra = false) {
+    constexpr int outstanding = (C::D - 1 < C::N - 1 - I) ? C::D - 1 : C::N - 1 - I;
+    if constexpr (EXTRA > 0) {  // only the wait differs between the two kinds of stage (wave-uniform `extra`)
+      if (extra)
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(outstanding + EXTRA));
+      else
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(outstanding));
+    } else {
+      asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(outstanding));
+    }
     __builtin_amdgcn_sched_barrier(0);
     constexpr int q = I / MT, t = I % MT;
     // fp64: operands swapped, the tile comes out transposed (TtmBody comment)
@@ -122,6 +150,9 @@ static __device__ __forceinline__ void run(const TtmArgs &a, const int m0, const
 
   const long long S = a.S;
   const int nAb = a.Ap >> 4;
+  // fp64 rolling flush: Q[s, :] is consumed once per s, by the flush that follows the last a-block of s: only that
+  // stage's buffer gets the Q row (one DMA instruction less in the other stages) and only that stage reads it
+  constexpr bool QLAST = (C::ES == 8) && (CALS_TTM_ROLL != 0) && (CALS_TTM_QLAST != 0);
   // 32-bit loop state (S is one mode's size): a 64-bit trip count made the compiler carry the stage
   // counter through VALU compares (v_cmp_le_i64, v_cndmask + v_readfirstlane) in every stage
   const int s_begin = (int)(S * tm / a.T);
@@ -139,10 +170,11 @@ static __device__ __forceinline__ void run(const TtmArgs &a, const int m0, const
   // ---- per-lane DMA source offsets (stage independent) ----
   // 32-bit BYTE offsets from wave-uniform bases: the DMA instructions take the scalar-base form
   // (global_load_lds_dwordx4 v_off, s[base:base+1]) -- no 64-bit VALU add and no address pair per piece
+  const int dw = (C::DW == 8) ? wave : wave - 4;  // index among the DMA-issuing waves (negative: issues none)
   unsigned src_off[C::NP];
 #pragma unroll
   for (int k = 0; k < C::NP; ++k) {
-    const int piece = k * 8 + wave;
+    const int piece = k * C::DW + dw;
     const int e = piece * C::PE + lane * (16 / C::ES);
     const int acol = e / C::LDL;
     const int m = e - acol * C::LDL;
@@ -154,7 +186,7 @@ static __device__ __forceinline__ void run(const TtmArgs &a, const int m0, const
   int p_dst[C::NPP];
 #pragma unroll
   for (int k = 0; k < C::NPP; ++k) {
-    const int pp = k * 8 + wave;       // P instruction pp: row pp / PPR, columns (pp % PPR) * PPE ...
+    const int pp = k * C::DW + dw;     // P instruction pp: row pp / PPR, columns (pp % PPR) * PPE ...
     const int row = pp / C::PPR;
     const int c0 = (pp % C::PPR) * C::PPE;
     p_src[k] = (unsigned)(row * CALS_BN + c0 + lane * (C::PLB / C::ES)) * (unsigned)C::ES;
@@ -163,7 +195,7 @@ static __device__ __forceinline__ void run(const TtmArgs &a, const int m0, const
   long long q_off;
   int q_byte;
   {
-    const int d = wave * C::QPE + (C::ES == 8 ? (lane >> 1) : lane);
+    const int d = (dw < 0 ? 0 : dw) * C::QPE + (C::ES == 8 ? (lane >> 1) : lane);
     int c = nb * CALS_BN + d;
     c = (c < a.R && d < CALS_BN) ? c : 0;
     q_off = a.ldQ * c;
@@ -172,31 +204,32 @@ static __device__ __forceinline__ void run(const TtmArgs &a, const int m0, const
   const long long slab_stride_s = (long long)a.Mp * a.Ap;
   const T *const Pt_nb = Pt + (long long)nb * a.Ap * CALS_BN;
 
-  auto issue_piece = [&]<int K>(const T *src_slab, const T *p_slab, const T *q_row, T *dst) {
+  // qn: the unit this DMA feeds is the LAST a-block of its s -- the only stage whose Q[s, :] is ever read (ROLL)
+  auto issue_piece = [&]<int K>(const T *src_slab, const T *p_slab, const T *q_row, T *dst, bool qn) {
     if constexpr (K < C::NP) {
-      const int piece = K * 8 + wave;
-      if (piece < C::PIECES && !DIAG(a.dbg & 16))  // CALS_DIAG, dbg 16 (timing only): no X DMA
+      const int piece = K * C::DW + dw;
+      if (piece < C::PIECES && !DIAG(a.dbg & 16) && !STRIP(16))  // CALS_DIAG, dbg 16 (timing only): no X DMA
         __builtin_amdgcn_global_load_lds(
             (const GLOBAL_AS void *)(reinterpret_cast<const char *>(src_slab) + (unsigned long long)src_off[K]),
             (LDS_AS void *)(dst + piece * C::PE), 16, 0, 0);
     } else if constexpr (K < C::NP + C::NPP) {
       constexpr int k = K - C::NP;
-      if (!DIAG(a.dbg & 8))  // CALS_DIAG, dbg 8 (timing only): no P DMA
+      if (!DIAG(a.dbg & 8) && !STRIP(8))  // CALS_DIAG, dbg 8 (timing only): no P DMA
       __builtin_amdgcn_global_load_lds(
           (const GLOBAL_AS void *)(reinterpret_cast<const char *>(p_slab) + (unsigned long long)p_src[k]),
           (LDS_AS void *)(dst + p_dst[k]), C::PLB, 0, 0);
-    } else if (wave < C::QPIECES) {
+    } else if (dw < C::QPIECES && qn) {
       const char *src = (const char *)(q_row + q_off) + q_byte;
       __builtin_amdgcn_global_load_lds((const GLOBAL_AS void *)src,
-                                       (LDS_AS void *)(dst + C::QOFF + wave * C::QPE), 4, 0, 0);
+                                       (LDS_AS void *)(dst + C::QOFF + dw * C::QPE), 4, 0, 0);
     }
   };
   // DMA instructions of MFMA step IS of the issuing half: K = IS, IS + HH, IS + 2 HH, ...
-  auto issue_at = [&]<int IS>(const T *src_slab, const T *p_slab, const T *q_row, T *dst) {
+  auto issue_at = [&]<int IS>(const T *src_slab, const T *p_slab, const T *q_row, T *dst, bool qn) {
     [&]<int... Ks>(std::integer_sequence<int, Ks...>) {
       (
           [&] {
-            if constexpr (Ks % C::HH == IS) issue_piece.template operator()<Ks>(src_slab, p_slab, q_row, dst);
+            if constexpr (Ks % C::HH == IS) issue_piece.template operator()<Ks>(src_slab, p_slab, q_row, dst, qn);
           }(),
           ...);
     }(std::make_integer_sequence<int, C::NDMA>{});
@@ -206,20 +239,22 @@ static __device__ __forceinline__ void run(const TtmArgs &a, const int m0, const
     const T *p_slab = Pt_nb + (long long)(16 * ab) * CALS_BN;
     const T *q_row = Qm + s;
     T *dst = lds + bufi * C::BUF;
+    const bool qn = !QLAST || ab == nAb - 1;
     [&]<int... Ks>(std::integer_sequence<int, Ks...>) {
-      (issue_piece.template operator()<Ks>(src_slab, p_slab, q_row, dst), ...);
+      (issue_piece.template operator()<Ks>(src_slab, p_slab, q_row, dst, qn), ...);
     }(std::make_integer_sequence<int, C::NDMA>{});
   };
 
   int ab_c = 0;
   int s_c = s_begin;
-  if (n_units > 0) issue_all(ab_c, s_c, 0);
+  const bool dma_wave = dw >= 0;
+  if (n_units > 0 && dma_wave) issue_all(ab_c, s_c, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   int ab_1 = ab_c + 1;
   int s_1 = s_c;
   if (ab_1 >= nAb) { ab_1 = 0; s_1++; }
-  if (n_units > 1) issue_all(ab_1, s_1, 1);
+  if (n_units > 1 && dma_wave) issue_all(ab_1, s_1, 1);
   int ab_2 = ab_1 + 1;
   int s_2 = s_1;
   if (ab_2 >= nAb) { ab_2 = 0; s_2++; }
@@ -238,7 +273,7 @@ static __device__ __forceinline__ void run(const TtmArgs &a, const int m0, const
       (unsigned)((C::QOFF + wave * 16 + (C::ES == 8 ? krow : lcol)) * C::ES);
   const unsigned p_lane_off = (unsigned)((C::POFF + krow * C::PP + wave * 16 + lcol) * C::ES);
   T *const Tout = static_cast<T *>(a.Tout);
-  const bool st = !DIAG(a.dbg & 1);  // CALS_DIAG, dbg 1 (timing only): no T stores
+  const bool st = !DIAG(a.dbg & 1) && !STRIP(1);  // CALS_DIAG, dbg 1 (timing only): no T stores
 
   // Columns R .. NB * 128 - 1 of the last column block are stored too (zeros: P is zero padded there;
   // the engine sizes T for whole column blocks): a per-lane column predicate costs every one of the
@@ -375,6 +410,8 @@ static __device__ __forceinline__ void run(const TtmArgs &a, const int m0, const
       const T *const dma_p = (fetch || !ALWAYS) ? p_slab : Pt_nb;
       const T *const dma_q = (fetch || !ALWAYS) ? q_row : safe_q;
       T *dst = lds + buf_nn * C::BUF;
+      const bool dma_qn = !QLAST || ab_2 == nAb - 1;   // (ab_2 still names unit iu + 2: advance() runs behind the issue)
+      const bool qstage = !QLAST || ab_c == nAb - 1;    // this stage reads Q
 
       if constexpr (LATE) {
         // barrier #iu at the start of slab iu: DMA(iu+1) landed everywhere, slab iu-1 is finished by
@@ -382,9 +419,9 @@ static __device__ __forceinline__ void run(const TtmArgs &a, const int m0, const
         // BEHIND this wait, so they never sit in front of it (vmcnt counts stores too).
         unsigned long long d0 = 0, d1 = 0, d2 = 0;
         if (DIAG(trace)) d0 = __builtin_amdgcn_s_memtime();
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (!STRIP(512)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (DIAG(trace)) d1 = __builtin_amdgcn_s_memtime();
-        __builtin_amdgcn_s_barrier();
+        if (!STRIP(128)) __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         if (DIAG(trace)) {
           d2 = __builtin_amdgcn_s_memtime();
@@ -414,10 +451,12 @@ static __device__ __forceinline__ void run(const TtmArgs &a, const int m0, const
           lds_read_off<T, 12 * C::ES>(qcur[3], bufb + q_lane_off);
         }
       }
-      lds_read_off<T, 0>(bq[0], bufb + p_lane_off);
-      lds_read_off<T, 4 * C::PP * C::ES>(bq[1], bufb + p_lane_off);
-      lds_read_off<T, 8 * C::PP * C::ES>(bq[2], bufb + p_lane_off);
-      lds_read_off<T, 12 * C::PP * C::ES>(bq[3], bufb + p_lane_off);
+      if (!STRIP(256) || iu == 0) {
+        lds_read_off<T, 0>(bq[0], bufb + p_lane_off);
+        lds_read_off<T, 4 * C::PP * C::ES>(bq[1], bufb + p_lane_off);
+        lds_read_off<T, 8 * C::PP * C::ES>(bq[2], bufb + p_lane_off);
+        lds_read_off<T, 12 * C::PP * C::ES>(bq[3], bufb + p_lane_off);
+      }
       P3::template preload<0>(ring, base);
       asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(C::D));  // Q and P landed (D younger reads in flight)
       __builtin_amdgcn_sched_barrier(0);
@@ -438,7 +477,7 @@ static __device__ __forceinline__ void run(const TtmArgs &a, const int m0, const
                 if (roll) {
 #pragma unroll
                   for (int r = 0; r < 4; ++r) {
-                    gacc[Is][r] += tacc[Is][r] * q_pend[r];
+                    if (!STRIP(32)) gacc[Is][r] += tacc[Is][r] * q_pend[r];
                     if (st)
                       asm volatile("global_store_dwordx2 %0, %1, %2 offset:%3 nt"
                                    :: "v"(tvo[r]), "v"(tacc[Is][r]), "s"(t_s), "i"(16 * Is * C::ES) : "memory");
@@ -448,17 +487,20 @@ static __device__ __forceinline__ void run(const TtmArgs &a, const int m0, const
                   tacc[Is] = (acc_t){0, 0, 0, 0};
                 }
                 P3::template step<Is>(tacc, ring, bq, base);
-                if constexpr (Is == QJ) {
+                if constexpr (Is == QJ && !STRIP(64)) if (qstage) {
                   lds_read_off<T, 0>(q_pend[0], bufb + q_lane_off);
                   lds_read_off<T, 4 * C::ES>(q_pend[1], bufb + q_lane_off);
                   lds_read_off<T, 8 * C::ES>(q_pend[2], bufb + q_lane_off);
                   lds_read_off<T, 12 * C::ES>(q_pend[3], bufb + q_lane_off);
                 }
+              } else if constexpr (ROLL && Is > QJ && Is <= QJ + C::D) {
+                // in a Q stage four Q reads were issued behind the ring read this step consumes
+                P3::template step<Is, 4>(tacc, ring, bq, base, qstage);
               } else {
-                P3::template step<Is, (ROLL && Is > QJ && Is <= QJ + C::D) ? 4 : 0>(tacc, ring, bq, base);
+                P3::template step<Is, 0>(tacc, ring, bq, base);
               }
               if constexpr (LATE && Is < C::HH) {
-                if (ALWAYS || fetch) issue_at.template operator()<Is>(dma_x, dma_p, dma_q, dst);
+                if (ALWAYS || fetch) issue_at.template operator()<Is>(dma_x, dma_p, dma_q, dst, dma_qn);
               }
               if constexpr (LATE && Is == (C::NDMA < C::H - 1 ? C::NDMA : C::H - 1)) advance();
             }(),
@@ -468,9 +510,9 @@ static __device__ __forceinline__ void run(const TtmArgs &a, const int m0, const
       if constexpr (!LATE) {
         unsigned long long d0 = 0, d1 = 0, d2 = 0;
         if (DIAG(trace)) d0 = __builtin_amdgcn_s_memtime();
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (!STRIP(512) && C::DW == 8) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (no DMA of its own: no wait)
         if (DIAG(trace)) d1 = __builtin_amdgcn_s_memtime();
-        __builtin_amdgcn_s_barrier();
+        if (!STRIP(128)) __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         if (DIAG(trace)) {
           d2 = __builtin_amdgcn_s_memtime();
@@ -488,11 +530,16 @@ static __device__ __forceinline__ void run(const TtmArgs &a, const int m0, const
         (
             [&] {
               constexpr int J = I0 + Is;  // step H + J
-              P3::template step<C::H + J, (ROLL && C::H + J <= QJ + C::D) ? 4 : 0>(tacc, ring, bq, base);
-              if constexpr (!LATE && J < C::HH) {
-                if (ALWAYS || fetch) issue_at.template operator()<J>(dma_x, dma_p, dma_q, dst);
+              if constexpr (ROLL && C::H + J <= QJ + C::D) {
+                P3::template step<C::H + J, 4>(tacc, ring, bq, base, qstage);
+              } else {
+                P3::template step<C::H + J, 0>(tacc, ring, bq, base);
               }
-              if constexpr (!LATE && J == (C::NDMA < C::N - C::H - 1 ? C::NDMA : C::N - C::H - 1)) advance();
+              if constexpr (!LATE && J < C::HH && C::DW == 8) {
+                if (ALWAYS || fetch) issue_at.template operator()<J>(dma_x, dma_p, dma_q, dst, dma_qn);
+              }
+              if constexpr (!LATE && J == (C::DW != 8 ? 0 : (C::NDMA < C::N - C::H - 1 ? C::NDMA : C::N - C::H - 1)))
+                advance();
             }(),
             ...);
       };
@@ -500,7 +547,7 @@ static __device__ __forceinline__ void run(const TtmArgs &a, const int m0, const
       // the last a-block of a mode whose size leaves at most 12 rows there (300 = 18 x 16 + 12): its
       // MFMAs would multiply zeros.  (Only when the DMA issue fits k-step 2, i.e. NDMA < MT.)
       second_half.template operator()<0>(std::make_integer_sequence<int, MT>{});
-      if (!(C::NDMA < MT && skip_q3 && ab_c == nAb - 1))
+      if (!((C::DW != 8 || C::NDMA < MT) && skip_q3 && ab_c == nAb - 1))
         second_half.template operator()<MT>(std::make_integer_sequence<int, C::N - C::H - MT>{});
       else  // the operand reads already issued for k-step 3 must land before their registers are reused
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

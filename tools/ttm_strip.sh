@@ -1,0 +1,27 @@
+#!/bin/bash
+# Timing-only stripping ladder of ttm_kernel at C3: variants compiled with -DCALS_TTM_STRIP=<mask> and prebuilt as
+# cp-cals_amd/build/variants/libcals_hip_strip<mask>.so (bits: ttm_kernel.hip; results of stripped runs are garbage
+# by design -- only the TTM's launch time is read).   bash tools/ttm_strip.sh <out_dir> <mask> [<mask> ...]
+OUT="${1:-gpurun_out/strip}"; shift
+mkdir -p "$OUT"
+LIB=cp-cals_amd/libcals_hip.so
+cp "$LIB" "$OUT/prod.so.keep"
+run() {
+  python bench.py --workload c3 --no-cpu-baseline --no-strong-leg --steady-steps 0 --steps 20 > "$OUT/strip_$1.json" 2> "$OUT/strip_$1.err"
+  python - "$OUT/strip_$1.json" $1 <<'PY'
+import json, sys
+try:
+    d = json.loads(open(sys.argv[1]).readline())
+    r = d["roofline"]
+    print("strip %5s: ttm %.4f ms  frac %.4f  (%.1f it/s)" % (sys.argv[2], r["avg_launch_ms"], r["frac"], d["value"]))
+except Exception as ex:
+    print("strip %5s: failed (%s)" % (sys.argv[2], ex))
+PY
+}
+run 0
+for m in "$@"; do
+  cp "cp-cals_amd/build/variants/libcals_hip_strip$m.so" "$LIB"
+  run $m
+done
+cp "$OUT/prod.so.keep" "$LIB"; rm -f "$OUT/prod.so.keep"
+run 0
