@@ -41,7 +41,8 @@ namespace calship {
 #endif
 // Timing-only stripping, compile time (results garbage; tools/ttm_strip.sh builds the variants): bit 1 no T stores,
 // 8 no P DMA, 16 no X DMA, 32 no flush FMAs, 64 no Q reads, 128 no stage barrier, 256 P operands read once,
-// 512 no vmcnt wait in front of the barrier.  (The run-time CALS_TTM_DBG bits of CALS_DIAG builds cost registers:
+// 512 no vmcnt wait in front of the barrier.  (A probe that ADDED a plain 16-byte-per-lane register
+// load per P piece showed that any vector-memory instruction costs what an LDS-DMA piece costs, profiles/r03_ttm_strip_ladder.txt.)  (The run-time CALS_TTM_DBG bits of CALS_DIAG builds cost registers:
 // the DIAG kernel spills and runs at half speed -- useless for this.)
 #ifndef CALS_TTM_STRIP
 #define CALS_TTM_STRIP 0
