@@ -598,6 +598,9 @@ static __device__ __forceinline__ void run(const TtmArgs &a, const int m0, const
       trace[3] = dg_n;
     }
   };
+#if defined(CALS_TTM_PRIO)  // experiment: static issue priority for one wave group (1: waves 4-7, 2: waves 0-3)
+  if ((CALS_TTM_PRIO == 1) == (wave >= 4)) __builtin_amdgcn_s_setprio(1);
+#endif
   if (wave < 4 && !DIAG(a.dbg & 2))
     unit_loop.template operator()<false>();
   else
