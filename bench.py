@@ -221,8 +221,13 @@ def main():
         raise SystemExit("bench.py needs a GPU: the CALS engine has no CPU fallback")
     if args.force_device0:
         local_rank = 0
-    if local_rank >= torch.cuda.device_count():
-        raise SystemExit("rank %d: LOCAL_RANK %d but only %d GPU(s) visible" % (rank, local_rank, torch.cuda.device_count()))
+    n_visible = torch.cuda.device_count()
+    if local_rank >= n_visible and n_visible == 1 and world > 1 and args.dist_backend == "nccl":
+        # a launcher that gives every rank its own GPU through *_VISIBLE_DEVICES shows each of them one device: use it.
+        # (On a box with ONE GPU for all ranks RCCL refuses the group -- "Duplicate GPU detected" -- right below.)
+        local_rank = 0
+    if local_rank >= n_visible:
+        raise SystemExit("rank %d: LOCAL_RANK %d but only %d GPU(s) visible" % (rank, local_rank, n_visible))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     pg_world = 1
