@@ -128,7 +128,7 @@ __device__ bool solve_passive(const double *Hs, int r, WaveScratch &ws, unsigned
   if (full || pas == ws.cached) {
     dg = full ? ws.dgf[p] : ws.dg;
     for (int j = 0; j < np; ++j) {  // L z = b with the cached factor, same operation order
-      const double zj = bcast(t, j) * bcast(dg, j);
+      const double zj = bcast(t * dg, j);  // lane j's product = bcast(t, j) * bcast(dg, j), one broadcast instead of two
       if (p == j)
         t = zj;
       else if (valid && p > j)
@@ -186,7 +186,7 @@ __device__ bool solve_passive(const double *Hs, int r, WaveScratch &ws, unsigned
   ws.dg = dg;
   }
   for (int j = np - 1; j >= 0; --j) {  // L^T x = z
-    const double xj = bcast(t, j) * bcast(dg, j);
+    const double xj = bcast(t * dg, j);
     if (p == j)
       t = xj;
     else if (valid && p < j)
@@ -400,6 +400,363 @@ __global__ void __launch_bounds__(256) nnls_kernel(const NnlsArgs a) {
     atomicAdd(a.dbg_counts + 5, (unsigned long long)n_full);
   }
 #endif
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Ranks <= 32: TWO ROWS PER WAVEFRONT (round 3).  With one row per wave a rank-20 row keeps 20 of 64 lanes busy and the
+// kernel is issue bound.  Here lanes 0-31 and 32-63 each run the algorithm above on a row of their own ("group" g =
+// lane >> 5, component l = lane & 31): what was wave-uniform -- the active / passive sets, loop counts, every
+// decision -- is group-uniform and lives in VGPRs; the two groups execute in lockstep wherever their rows take the
+// same path (both all-passive with a cached factor: the common case on non-negative data) and under the hardware's
+// execution mask where they do not.  Measured at C3's shape (tools/nnls_bench.py): update stage 0.857 -> 0.704 ms per
+// sweep, 208.6 -> 216.8 it/s -- far from 2x: a row is a chain of dependent steps (broadcast, LDS read, FMA), and with
+// two tiles per wave fewer workgroups fit a CU, so the rows in flight per CU only grow from 24 to 32.  Same operations in the same order per row as nnls_kernel, hence the same
+// results bit for bit; reductions run over 32 lanes (xor offsets 16..1 never leave a group), a broadcast from
+// component j reads lanes j and 32 + j (v_readlane ignores the execution mask) and selects by group.
+// ---------------------------------------------------------------------------------------------------
+namespace {
+
+__device__ __forceinline__ double gbcast(double v, int j, int g) {  // j uniform over the active lanes
+#ifndef CALS_NNLS2_READLANE  // the LDS crossbar: two ds_bpermute_b32 (measured 0.704 ms of update stage per sweep at
+  // C3's shape against 0.736 with the four v_readlane + two selects below)
+  const int src = ((g << 5) | j) << 2;
+  return __hiloint2double(__builtin_amdgcn_ds_bpermute(src, __double2hiint(v)),
+                          __builtin_amdgcn_ds_bpermute(src, __double2loint(v)));
+#endif
+  const int lo0 = __builtin_amdgcn_readlane(__double2loint(v), j), hi0 = __builtin_amdgcn_readlane(__double2hiint(v), j);
+  const int lo1 = __builtin_amdgcn_readlane(__double2loint(v), j + 32),
+            hi1 = __builtin_amdgcn_readlane(__double2hiint(v), j + 32);
+  return __hiloint2double(g ? hi1 : hi0, g ? lo1 : lo0);
+}
+__device__ __forceinline__ double gmin(double v) {
+#pragma unroll
+  for (int off = 16; off > 0; off >>= 1) v = fmin(v, __shfl_xor(v, off));
+  return v;
+}
+__device__ __forceinline__ double gmax(double v) {
+#pragma unroll
+  for (int off = 16; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off));
+  return v;
+}
+__device__ __forceinline__ double gadd(double v) {
+#pragma unroll
+  for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+__device__ __forceinline__ unsigned gballot(bool p, int g) {
+  const unsigned long long b = __ballot(p);
+  return g ? (unsigned)(b >> 32) : (unsigned)b;
+}
+
+// the larger of the two groups' n (a group is wholly active or wholly idle): a loop counter that STARTS from a
+// group-dependent value must be made wave-uniform, because v_readlane takes its lane from a scalar
+__device__ __forceinline__ int gmax_int(int n) {
+  const unsigned long long b = __ballot(true);
+  const int n0 = (b & 1ull) ? __builtin_amdgcn_readlane(n, 0) : 0;
+  const int n1 = ((b >> 32) & 1ull) ? __builtin_amdgcn_readlane(n, 32) : 0;
+  return n0 > n1 ? n0 : n1;
+}
+
+struct GroupScratch {
+  unsigned cached;  // passive set whose factor is in Lw / dg (0: none)
+  double dg;        // lane p of the group: 1 / L[p][p] of that factor
+  double *Lw;       // the group's tile: strict lower triangle, row p at Lw + p * ldw
+  int ldw;
+  int *idx;
+  double *cv, *xs;
+  const double *Lf, *dgf;  // the workgroup's factor of the full set
+  unsigned fmask;
+};
+
+// solve_passive for one group (l = component / compacted position, g = group).  pas, np group-uniform.
+__device__ bool gsolve(const double *Hs, int r, GroupScratch &gs, unsigned pas, int np, double y, int l, int g, double &x) {
+  const bool mine = (pas >> l) & 1u;
+  if (mine) {
+    const int pos = __popc(pas & ((1u << l) - 1u));
+    gs.idx[pos] = l;
+    gs.cv[pos] = y;
+  }
+  WAVE_SYNC();
+  const int p = l;
+  const bool valid = p < np;
+  const int myi = valid ? gs.idx[p] : 0;
+  double t = valid ? gs.cv[p] : 0.0;
+  double dg = 1.0;
+  double *Lw = gs.Lw;
+  const int ldw = gs.ldw;
+  const bool full = gs.fmask && pas == gs.fmask;
+  const double *Ls = full ? gs.Lf : Lw;
+  bool ok = true;
+  if (full || pas == gs.cached) {
+    dg = full ? gs.dgf[p] : gs.dg;
+    for (int j = 0; j < np; ++j) {  // L z = b with the cached factor
+      const double zj = gbcast(t * dg, j, g);
+      if (p == j)
+        t = zj;
+      else if (valid && p > j)
+        t -= Ls[p * ldw + j] * zj;
+    }
+  } else {
+    gs.cached = 0;
+    for (int j = 0; j < np; ++j) {
+      const int ij = gs.idx[j];  // the same address for every lane of the group
+      const bool below = valid && p > j;
+      const int lrow = below ? p : j;
+      double ajj = Hs[ij + r * ij];
+      double sv = Hs[(below ? myi : ij) + r * ij];
+      const double *rj = Lw + j * ldw, *ri = Lw + lrow * ldw;
+      int k = 0;
+      for (; k + 4 <= j; k += 4) {
+        const double l0 = rj[k], l1 = rj[k + 1], l2 = rj[k + 2], l3 = rj[k + 3];
+        const double m0 = ri[k], m1 = ri[k + 1], m2 = ri[k + 2], m3 = ri[k + 3];
+        ajj -= l0 * l0;
+        ajj -= l1 * l1;
+        ajj -= l2 * l2;
+        ajj -= l3 * l3;
+        sv -= m0 * l0;
+        sv -= m1 * l1;
+        sv -= m2 * l2;
+        sv -= m3 * l3;
+      }
+      for (; k < j; ++k) {
+        const double ljk = rj[k];
+        ajj -= ljk * ljk;
+        sv -= ri[k] * ljk;
+      }
+      if (!(ajj > 0.0)) {  // group-uniform: every lane of the group computed the same a_jj
+        ok = false;
+        break;
+      }
+      double rl = __builtin_amdgcn_rsq(ajj);
+      rl = rl * fma(-0.5 * ajj * rl, rl, 1.5);
+      rl = rl * fma(-0.5 * ajj * rl, rl, 1.5);
+      const double lij = sv * rl;
+      if (below) Lw[p * ldw + j] = lij;
+      const double zj = gbcast(t, j, g) * rl;
+      if (p == j) {
+        t = zj;
+        dg = rl;
+      } else if (below) {
+        t -= lij * zj;
+      }
+      WAVE_SYNC();
+    }
+    if (ok) {
+      gs.cached = pas;
+      gs.dg = dg;
+    }
+  }
+  if (ok) {
+    // L^T x = z.  The column counter runs down from the LARGER passive set of the two groups (the ascending loops
+    // above start at 0 together; this one would start at two different columns and v_readlane reads one lane)
+    for (int j = gmax_int(np) - 1; j >= 0; --j) {
+      if (j < np) {
+        const double xj = gbcast(t * dg, j, g);
+        if (p == j)
+          t = xj;
+        else if (valid && p < j)
+          t -= Ls[j * ldw + p] * xj;
+      }
+    }
+    if (valid) gs.xs[myi] = t;
+  }
+  WAVE_SYNC();
+  x = (ok && mine) ? gs.xs[l] : 0.0;
+  WAVE_SYNC();
+  return ok;
+}
+
+__device__ __forceinline__ double gmultipliers(const double *Hs, int r, double y, double d, int l, int g) {
+  double acc = 0.0;
+  const int i = l < r ? l : 0;
+  for (int j = 0; j < r; ++j) acc += Hs[i + r * j] * gbcast(d, j, g);
+  return y - acc;
+}
+
+}  // namespace
+
+template <typename T>
+__global__ void __launch_bounds__(256) nnls2_kernel(const NnlsArgs a) {
+  const int k_model = blockIdx.x / a.chunks, chunk = blockIdx.x % a.chunks;
+  const int slot = a.slots[k_model];
+  const int r = a.mt.rank[slot], col = a.mt.col[slot];
+  if (r < a.rlo || r > a.rhi) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 5, l = lane & 31;
+  const int W = blockDim.x >> 6;
+  const int I = a.I;
+
+  double *Hs = reinterpret_cast<double *>(nnls_dyn);  // r x r, ld = r
+  GroupScratch gs;
+  gs.cached = 0;
+  gs.dg = 1.0;
+  const int ldw = r | 1;
+  {
+    const size_t tile = (size_t)a.rmax * (a.rmax | 1);
+    const size_t per_group = tile + 32 + 32 + 16;  // doubles (idx: 32 ints)
+    double *shared_f = Hs + (size_t)a.rmax * a.rmax;
+    double *base = shared_f + tile + 32 + per_group * (size_t)(2 * wave + g);
+    gs.Lf = shared_f;
+    gs.dgf = shared_f + tile;
+    gs.fmask = 0;
+    gs.Lw = base;
+    gs.ldw = ldw;
+    gs.cv = base + tile;
+    gs.xs = gs.cv + 32;
+    gs.idx = reinterpret_cast<int *>(gs.xs + 32);
+  }
+  for (int e = tid; e < r * r; e += blockDim.x) {
+    const int i = e % r, j = e / r;
+    double h = 1.0;
+    for (int m = 0; m < a.n_modes; ++m)
+      if (m != a.mode) h *= a.gram[m][i + CALS_GLD * (long long)(col + j)];
+    Hs[i + r * j] = h;
+  }
+  __syncthreads();
+  double tol;
+  {
+    double cs = -DBL_MAX;
+    if (l < r) {
+      cs = 0.0;
+      for (int i = 0; i < r; ++i) cs += fabs(Hs[i + r * l]);
+    }
+    tol = 10 * 2.2204e-16 * gmax(cs) * (double)r;
+  }
+  const unsigned rmask = (r >= 32) ? ~0u : ((1u << r) - 1u);
+  {  // group 0 of wave 0 factors the full set into the shared tile
+    __shared__ int s_full_ok2;
+    if (wave == 0 && g == 0) {
+      GroupScratch gf = gs;
+      gf.Lw = const_cast<double *>(gs.Lf);
+      double unused;
+      const bool ok = gsolve(Hs, r, gf, rmask, r, 0.0, l, 0, unused);
+      if (ok) const_cast<double *>(gs.dgf)[l] = gf.dg;
+      if (l == 0) s_full_ok2 = ok ? 1 : 0;
+    }
+    __syncthreads();
+    if (s_full_ok2) gs.fmask = rmask;
+  }
+  T *fac = static_cast<T *>(a.factor) + (long long)I * col;
+  unsigned long long *actp = a.act + (long long)I * col;
+  double *rowdot = a.rowdot + (long long)I * k_model;
+  const int rows_per = (I + a.chunks - 1) / a.chunks;
+  const int row0 = chunk * rows_per, row1 = min(I, row0 + rows_per);
+  int status = 0;
+
+#ifdef CALS_NNLS2_SINGLE  // debugging: group 0 alone, one row per wave
+  for (int rb = row0 + wave; rb < row1; rb += W) {
+    const int row = rb;
+    if (g == 0) {
+#else
+  for (int rb = row0 + 2 * wave; rb < row1; rb += 2 * W) {
+    const int row = rb + g;
+    if (row < row1) {  // (the odd row of a chunk's tail leaves group 1 idle)
+#endif
+      const bool in = l < r;
+      const double y = in ? (double)fac[row + (long long)I * l] : 0.0;
+      unsigned act = (unsigned)actp[row] & rmask;
+      act &= ~gballot(in && y > 0.0, g);
+      double d = 0.0, sp = 0.0;
+      int budget = NNLS_MAX_EXCHANGES(r);
+      unsigned pas = ~act & rmask;
+      if (pas) {  // warm start (update.cpp:93-121)
+        bool failed = !gsolve(Hs, r, gs, pas, __popc(pas), y, l, g, sp);
+        if (!failed) {
+          d = sp;
+          for (;;) {
+            const bool ip = (pas >> l) & 1u;
+            if (!(gmin(ip ? sp : DBL_MAX) <= tol)) break;
+            const bool z = in && d <= tol;
+            if (z) d = 0.0;
+            act |= gballot(z, g);
+            pas = ~act & rmask;
+            if (!pas) {  // ZeroPassiveSet
+              failed = true;
+              break;
+            }
+            if (!gsolve(Hs, r, gs, pas, __popc(pas), y, l, g, sp)) {
+              failed = true;
+              break;
+            }
+            d = sp;
+            if (--budget <= 0) {
+              status |= 2;
+              break;
+            }
+          }
+        }
+        if (failed) {
+          act = rmask;
+          d = 0.0;
+        }
+      }
+      double w = gmultipliers(Hs, r, y, d, l, g);
+      for (;;) {  // main loop (update.cpp:126-167)
+        if (!act || budget <= 0) break;
+        const bool ia = (act >> l) & 1u;
+        const double wmax = gmax(ia ? w : -DBL_MAX);
+        if (!(wmax > tol)) break;
+        const unsigned hit = gballot(ia && w == wmax, g);
+        const int m = __ffs((int)hit) - 1;  // Tensor::max_id: the first of equal maxima
+        const unsigned act_top = act;
+        act &= ~(1u << m);
+        pas = ~act & rmask;
+        if (!gsolve(Hs, r, gs, pas, __popc(pas), y, l, g, sp)) {
+          status |= 1;
+          break;
+        }
+        bool stop = false;
+        for (;;) {  // inner loop (update.cpp:136-157)
+          const bool ip = (pas >> l) & 1u;
+          if (!(gmin(ip ? sp : DBL_MAX) <= tol)) break;
+          const double alpha = gmin((ip && sp <= tol) ? d / (d - sp) : DBL_MAX);
+          if (in) d = d + alpha * (sp - d);
+          const bool na = ip && fabs(d) < tol;
+          if (na) d = 0.0;
+          act |= gballot(na, g);
+          pas = ~act & rmask;
+          if (!pas) {
+            status |= 2;
+            stop = true;
+            break;
+          }
+          if (!gsolve(Hs, r, gs, pas, __popc(pas), y, l, g, sp)) {
+            status |= 1;
+            stop = true;
+            break;
+          }
+          if (--budget <= 0) {
+            status |= 2;
+            break;
+          }
+        }
+        if (stop) break;
+        d = sp;
+        w = gmultipliers(Hs, r, y, d, l, g);
+        if (act == act_top) {  // the pass reproduced its own starting state: the reference's loop never ends here
+          status |= 2;
+          break;
+        }
+        if (--budget <= 0) {
+          status |= 2;
+          break;
+        }
+      }
+      if (in) fac[row + (long long)I * l] = (T)d;
+      const double dot = gadd(in ? d * y : 0.0);
+      if (l == 0) {
+        actp[row] = (unsigned long long)act;
+        rowdot[row] = dot;
+      }
+    }
+  }
+  if (status && l == 0) atomicOr(a.status, status);
+}
+
+size_t nnls2_lds_bytes(int rmax, int waves) {
+  const size_t tile = (size_t)rmax * (rmax | 1);
+  const size_t per_group = tile + 32 + 32 + 16;
+  return ((size_t)rmax * rmax + tile + 32 + per_group * 2 * waves) * sizeof(double);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -869,18 +1226,32 @@ hipError_t nnls_launch(const NnlsArgs &a_in, hipStream_t st) {
       a.rhi = CALS_RMAX;
     }
     a.rmax = std::min(a.rhi, std::min(std::max(a_in.rmax, 1), CALS_RMAX));
+    static const bool one_row = getenv("CALS_NNLS_ONE_ROW") != nullptr;  // A/B switch: one row per wave everywhere
+    const bool two_rows = a.rhi <= 32 && !one_row;                       // ranks <= 32: two rows per wavefront
     int waves = 4;
-    while (waves > 1 && nnls_lds_bytes(a.rmax, waves) > budget) --waves;
-    const size_t dyn = nnls_lds_bytes(a.rmax, waves);
+    while (waves > 1 && (two_rows ? nnls2_lds_bytes(a.rmax, waves) : nnls_lds_bytes(a.rmax, waves)) > budget) --waves;
+    const size_t dyn = two_rows ? nnls2_lds_bytes(a.rmax, waves) : nnls_lds_bytes(a.rmax, waves);
     // rows per workgroup: at least 4 per wave, enough workgroups to fill 256 CUs several times over
     a.chunks = std::max(1, std::min((a.I + 4 * waves - 1) / (4 * waves), (4096 + a.n_slots - 1) / a.n_slots));
     static const int forced_chunks = getenv("CALS_NNLS_CHUNKS") ? atoi(getenv("CALS_NNLS_CHUNKS")) : 0;  // experiments
     if (forced_chunks > 0) a.chunks = std::min(forced_chunks, a.I);
     const dim3 grid((unsigned)(a.n_slots * a.chunks)), block(64 * waves);
-    if (di)
+    if (two_rows) {
+      const void *fn2 = di ? reinterpret_cast<const void *>(&nnls2_kernel<float>)
+                           : reinterpret_cast<const void *>(&nnls2_kernel<double>);
+      static AttrOnce once2[2];
+      const hipError_t e2 = once2[di].ensure(
+          [&] { return hipFuncSetAttribute(fn2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)budget); });
+      if (e2 != hipSuccess) return e2;
+      if (di)
+        hipLaunchKernelGGL(nnls2_kernel<float>, grid, block, dyn, st, a);
+      else
+        hipLaunchKernelGGL(nnls2_kernel<double>, grid, block, dyn, st, a);
+    } else if (di) {
       hipLaunchKernelGGL(nnls_kernel<float>, grid, block, dyn, st, a);
-    else
+    } else {
       hipLaunchKernelGGL(nnls_kernel<double>, grid, block, dyn, st, a);
+    }
   }
   if (huge) {  // the models above CALS_RMAX; every other workgroup returns at once
     a.chunks = nnls_huge_chunks(a.I);
