@@ -286,20 +286,20 @@ void adjust_edges(cals_hip_engine *e) { e->end = active_cols_of(e->occ.data(), e
 
 // MultiKtensor::check_availability, src/multi_ktensor.cpp:14-39
 int64_t first_fit(const int64_t *occ, int64_t n, int64_t rank) {
-  int64_t comp_counter = 0, pos_index = -1, prev_occ = -1;
-  for (int64_t i = 0; i < n; i++) {
-    if (comp_counter == rank) break;
-    if (occ[i] == 0 && prev_occ != 0) {
-      pos_index = i;
-      comp_counter++;
-    } else if (occ[i] == 0 && prev_occ == 0)
-      comp_counter++;
-    else
-      comp_counter = 0;
-    prev_occ = occ[i];
+  // left-to-right scan for the first run of `rank` free cells (the reference counts the cells of the current free
+  // run and remembers where it began; tests/test_abi_and_host_logic.py holds this scan against a literal restatement
+  // of that loop on random occupancy vectors, and the oracle carries the literal form too)
+  if (rank < 1) return -1;
+  int64_t run_begin = -1, run_length = 0;
+  for (int64_t cell = 0; cell < n; cell++) {
+    if (occ[cell] != 0) {
+      run_length = 0;
+      continue;
+    }
+    if (run_length == 0) run_begin = cell;
+    if (++run_length == rank) return run_begin;
   }
-  if (pos_index == -1 || comp_counter != rank) return -1;
-  return pos_index;
+  return -1;
 }
 int64_t check_availability(const cals_hip_engine *e, int64_t rank) {
   return first_fit(e->occ.data(), e->buffer, rank);
