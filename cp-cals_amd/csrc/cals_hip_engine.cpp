@@ -169,6 +169,8 @@ struct cals_hip_engine {
   ModelTable mt{};
   int max_slots = 0;
   int *d_slots = nullptr;
+  int *d_cls_idx = nullptr;   // registry positions sorted by NNLS rank class (nnls_rank_class): a class launch's
+  int cls_off[8] = {0};       // workgroups are exactly its models -- positions [cls_off[k], cls_off[k + 1])
   bool slots_dirty = true;
   std::vector<int> free_slots;
 
@@ -398,6 +400,18 @@ int upload_slots(cals_hip_engine *e) {
     size_t k = 0;
     for (auto t : e->registry) s[k++] = e->models[t].slot;
     HIPCHK(hipMemcpyAsync(e->d_slots, s, k * sizeof(int), hipMemcpyHostToDevice, e->stream));
+    // the same registry positions grouped by rank class (counting sort, registry order kept inside a class)
+    int *ci = nullptr;
+    if ((rc = arena_alloc(e, e->registry.size() * sizeof(int), (void **)&ci))) return rc;
+    int cnt[8] = {0};
+    for (auto t : e->registry) cnt[nnls_rank_class((int)e->models[t].rank)]++;
+    e->cls_off[0] = 0;
+    for (int c = 0; c < 7; c++) e->cls_off[c + 1] = e->cls_off[c] + cnt[c];
+    int fill[8];
+    for (int c = 0; c < 8; c++) fill[c] = e->cls_off[c];
+    int pos = 0;
+    for (auto t : e->registry) ci[fill[nnls_rank_class((int)e->models[t].rank)]++] = pos++;
+    HIPCHK(hipMemcpyAsync(e->d_cls_idx, ci, e->registry.size() * sizeof(int), hipMemcpyHostToDevice, e->stream));
   }
   e->slots_dirty = false;
   return CALS_HIP_OK;
@@ -960,6 +974,8 @@ int sweep_once(cals_hip_engine *e, bool evict_enabled, bool defer_changed = fals
       q.status = e->d_nnls_status;
       q.rmax = rank_max;
       q.rank_classes = rank_classes;
+      q.cls_idx = e->d_cls_idx;
+      for (int c = 0; c < 8; c++) q.cls_off[c] = e->cls_off[c];
       q.dbg_counts = e->dbg_trace ? e->dbg_trace + 8 * 2048 + 1024 : nullptr;  // CALS_DIAG + CALS_TTM_TRACE: row / solve counters
       q.hscratch = e->nnls_hscratch;
       q.hcounter = e->d_hcounter;
@@ -1730,6 +1746,7 @@ int cals_hip_create_ex(cals_hip_engine **out, int n_modes, const int64_t *modes,
   if ((rc = dev_alloc(e, &e->mt.bk_iters, ms))) return rc;
   if ((rc = dev_alloc(e, &e->mt.flags, ms))) return rc;
   if ((rc = dev_alloc(e, &e->d_slots, ms))) return rc;
+  if ((rc = dev_alloc(e, &e->d_cls_idx, ms))) return rc;
   if ((rc = dev_alloc(e, &e->d_jk_norms, (size_t)modes[0]))) return rc;
   e->h_flags.assign(ms, 0);
   e->h_iters.assign(ms, 0);
@@ -1879,6 +1896,7 @@ int cals_hip_destroy(cals_hip_engine *e) {
   fr(e->mt.bk_iters);
   fr(e->mt.flags);
   fr(e->d_slots);
+  fr(e->d_cls_idx);
   for (auto &p : e->ev_pool) {
     (void)hipEventDestroy(p.a);
     (void)hipEventDestroy(p.b);

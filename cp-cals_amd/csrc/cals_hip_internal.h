@@ -196,6 +196,10 @@ struct NnlsArgs {
   int *status;         // sticky OR: 1 Cholesky failure in the main loop, 2 exchange bound reached
   int rmax;            // largest rank in flight (sizes the LDS tiles)
   unsigned rank_classes;  // bit k: a model of nnls_rank_class k is in flight (0: one launch sized by rmax)
+  const int *cls_idx;  // registry positions sorted by nnls_rank_class (or nullptr: every launch walks all models and
+  int cls_off[8];      // the other classes' workgroups return at once); class k = positions [cls_off[k], cls_off[k+1])
+  const int *idx;      // set by nnls_launch: this launch's models (registry positions), n_cls of them; nullptr = all
+  int n_cls;
   int rlo, rhi;        // set by nnls_launch: the ranks this launch serves
   int chunks;          // set by nnls_launch: workgroups per model
   unsigned long long *dbg_counts;  // CALS_DIAG builds: {rows, solves, factorisations, main-loop passes, inner passes}
@@ -203,7 +207,7 @@ struct NnlsArgs {
   int *hcounter;       // zero at launch: blocks are handed out in arrival order
 };
 hipError_t nnls_launch(const NnlsArgs &a, hipStream_t st);
-int nnls_rank_class(int r);  // 0: <= 24, 1: <= 32, 2: <= 48, 3: <= 64, 4: above (nnls_huge_kernel)
+int nnls_rank_class(int r);  // 0: <= 16, 1: <= 24, 2: <= 32, 3: <= 48, 4: <= 64, 5: above (nnls_huge_kernel)
 size_t nnls_huge_block_doubles();
 int nnls_huge_chunks(int I);
 struct NnlsResetArgs {

@@ -213,7 +213,8 @@ extern __shared__ __attribute__((aligned(16))) unsigned char nnls_dyn[];
 
 template <typename T>
 __global__ void __launch_bounds__(256) nnls_kernel(const NnlsArgs a) {
-  const int k_model = blockIdx.x / a.chunks, chunk = blockIdx.x % a.chunks;
+  const int k_pos = blockIdx.x / a.chunks, chunk = blockIdx.x % a.chunks;
+  const int k_model = a.idx ? a.idx[k_pos] : k_pos;  // registry position (a class launch lists its own models)
   const int slot = a.slots[k_model];
   const int r = a.mt.rank[slot], col = a.mt.col[slot];
   if (r < a.rlo || r > a.rhi) return;  // another launch's rank class (nnls_launch)
@@ -403,58 +404,63 @@ __global__ void __launch_bounds__(256) nnls_kernel(const NnlsArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Ranks <= 32: TWO ROWS PER WAVEFRONT (round 3).  With one row per wave a rank-20 row keeps 20 of 64 lanes busy and the
-// kernel is issue bound.  Here lanes 0-31 and 32-63 each run the algorithm above on a row of their own ("group" g =
-// lane >> 5, component l = lane & 31): what was wave-uniform -- the active / passive sets, loop counts, every
+// Ranks <= 32: SEVERAL ROWS PER WAVEFRONT (round 3): two for ranks 17..32 (GS = 32 lanes per row), four for ranks <= 16
+// (GS = 16).  With one row per wave a rank-20 row keeps 20 of 64 lanes busy and the kernel is issue bound.  Here every
+// group of GS lanes runs the algorithm above on a row of its own ("group" g = lane / GS, component l = lane % GS): what
+// was wave-uniform -- the active / passive sets, loop counts, every
 // decision -- is group-uniform and lives in VGPRs; the two groups execute in lockstep wherever their rows take the
 // same path (both all-passive with a cached factor: the common case on non-negative data) and under the hardware's
 // execution mask where they do not.  Measured at C3's shape (tools/nnls_bench.py): update stage 0.857 -> 0.704 ms per
 // sweep, 208.6 -> 216.8 it/s -- far from 2x: a row is a chain of dependent steps (broadcast, LDS read, FMA), and with
 // two tiles per wave fewer workgroups fit a CU, so the rows in flight per CU only grow from 24 to 32.  Same operations in the same order per row as nnls_kernel, hence the same
-// results bit for bit; reductions run over 32 lanes (xor offsets 16..1 never leave a group), a broadcast from
-// component j reads lanes j and 32 + j (v_readlane ignores the execution mask) and selects by group.
+// results bit for bit; reductions run over GS lanes (xor offsets GS/2..1 never leave a group), a broadcast from
+// component j goes through the LDS crossbar (ds_bpermute, source lane GS g + j).
 // ---------------------------------------------------------------------------------------------------
 namespace {
 
+template <int GS>
 __device__ __forceinline__ double gbcast(double v, int j, int g) {  // j uniform over the active lanes
-#ifndef CALS_NNLS2_READLANE  // the LDS crossbar: two ds_bpermute_b32 (measured 0.704 ms of update stage per sweep at
-  // C3's shape against 0.736 with the four v_readlane + two selects below)
-  const int src = ((g << 5) | j) << 2;
+  // (GS = 32 also ran as four v_readlane + two selects: 0.736 ms of update stage per sweep at C3's shape against 0.704)
+  const int src = (g * GS + j) << 2;
   return __hiloint2double(__builtin_amdgcn_ds_bpermute(src, __double2hiint(v)),
                           __builtin_amdgcn_ds_bpermute(src, __double2loint(v)));
-#endif
-  const int lo0 = __builtin_amdgcn_readlane(__double2loint(v), j), hi0 = __builtin_amdgcn_readlane(__double2hiint(v), j);
-  const int lo1 = __builtin_amdgcn_readlane(__double2loint(v), j + 32),
-            hi1 = __builtin_amdgcn_readlane(__double2hiint(v), j + 32);
-  return __hiloint2double(g ? hi1 : hi0, g ? lo1 : lo0);
 }
+template <int GS>
 __device__ __forceinline__ double gmin(double v) {
 #pragma unroll
-  for (int off = 16; off > 0; off >>= 1) v = fmin(v, __shfl_xor(v, off));
+  for (int off = GS / 2; off > 0; off >>= 1) v = fmin(v, __shfl_xor(v, off));
   return v;
 }
+template <int GS>
 __device__ __forceinline__ double gmax(double v) {
 #pragma unroll
-  for (int off = 16; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off));
+  for (int off = GS / 2; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off));
   return v;
 }
+template <int GS>
 __device__ __forceinline__ double gadd(double v) {
 #pragma unroll
-  for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  for (int off = GS / 2; off > 0; off >>= 1) v += __shfl_xor(v, off);
   return v;
 }
+template <int GS>
 __device__ __forceinline__ unsigned gballot(bool p, int g) {
   const unsigned long long b = __ballot(p);
-  return g ? (unsigned)(b >> 32) : (unsigned)b;
+  return (unsigned)(b >> (GS * g)) & (GS == 32 ? ~0u : ((1u << GS) - 1u));
 }
 
 // the larger of the two groups' n (a group is wholly active or wholly idle): a loop counter that STARTS from a
 // group-dependent value must be made wave-uniform, because v_readlane takes its lane from a scalar
+template <int GS>
 __device__ __forceinline__ int gmax_int(int n) {
   const unsigned long long b = __ballot(true);
-  const int n0 = (b & 1ull) ? __builtin_amdgcn_readlane(n, 0) : 0;
-  const int n1 = ((b >> 32) & 1ull) ? __builtin_amdgcn_readlane(n, 32) : 0;
-  return n0 > n1 ? n0 : n1;
+  int m = 0;
+#pragma unroll
+  for (int k = 0; k < 64 / GS; ++k) {
+    const int nk = ((b >> (GS * k)) & 1ull) ? __builtin_amdgcn_readlane(n, GS * k) : 0;
+    m = nk > m ? nk : m;
+  }
+  return m;
 }
 
 struct GroupScratch {
@@ -469,6 +475,7 @@ struct GroupScratch {
 };
 
 // solve_passive for one group (l = component / compacted position, g = group).  pas, np group-uniform.
+template <int GS>
 __device__ bool gsolve(const double *Hs, int r, GroupScratch &gs, unsigned pas, int np, double y, int l, int g, double &x) {
   const bool mine = (pas >> l) & 1u;
   if (mine) {
@@ -490,7 +497,7 @@ __device__ bool gsolve(const double *Hs, int r, GroupScratch &gs, unsigned pas, 
   if (full || pas == gs.cached) {
     dg = full ? gs.dgf[p] : gs.dg;
     for (int j = 0; j < np; ++j) {  // L z = b with the cached factor
-      const double zj = gbcast(t * dg, j, g);
+      const double zj = gbcast<GS>(t * dg, j, g);
       if (p == j)
         t = zj;
       else if (valid && p > j)
@@ -532,7 +539,7 @@ __device__ bool gsolve(const double *Hs, int r, GroupScratch &gs, unsigned pas, 
       rl = rl * fma(-0.5 * ajj * rl, rl, 1.5);
       const double lij = sv * rl;
       if (below) Lw[p * ldw + j] = lij;
-      const double zj = gbcast(t, j, g) * rl;
+      const double zj = gbcast<GS>(t, j, g) * rl;
       if (p == j) {
         t = zj;
         dg = rl;
@@ -549,9 +556,9 @@ __device__ bool gsolve(const double *Hs, int r, GroupScratch &gs, unsigned pas, 
   if (ok) {
     // L^T x = z.  The column counter runs down from the LARGER passive set of the two groups (the ascending loops
     // above start at 0 together; this one would start at two different columns and v_readlane reads one lane)
-    for (int j = gmax_int(np) - 1; j >= 0; --j) {
+    for (int j = gmax_int<GS>(np) - 1; j >= 0; --j) {
       if (j < np) {
-        const double xj = gbcast(t * dg, j, g);
+        const double xj = gbcast<GS>(t * dg, j, g);
         if (p == j)
           t = xj;
         else if (valid && p < j)
@@ -566,23 +573,26 @@ __device__ bool gsolve(const double *Hs, int r, GroupScratch &gs, unsigned pas, 
   return ok;
 }
 
+template <int GS>
 __device__ __forceinline__ double gmultipliers(const double *Hs, int r, double y, double d, int l, int g) {
   double acc = 0.0;
   const int i = l < r ? l : 0;
-  for (int j = 0; j < r; ++j) acc += Hs[i + r * j] * gbcast(d, j, g);
+  for (int j = 0; j < r; ++j) acc += Hs[i + r * j] * gbcast<GS>(d, j, g);
   return y - acc;
 }
 
 }  // namespace
 
-template <typename T>
+template <typename T, int GS>
 __global__ void __launch_bounds__(256) nnls2_kernel(const NnlsArgs a) {
-  const int k_model = blockIdx.x / a.chunks, chunk = blockIdx.x % a.chunks;
+  constexpr int NG = 64 / GS;  // rows per wavefront
+  const int k_pos = blockIdx.x / a.chunks, chunk = blockIdx.x % a.chunks;
+  const int k_model = a.idx ? a.idx[k_pos] : k_pos;  // registry position (a class launch lists its own models)
   const int slot = a.slots[k_model];
   const int r = a.mt.rank[slot], col = a.mt.col[slot];
   if (r < a.rlo || r > a.rhi) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int g = lane >> 5, l = lane & 31;
+  const int g = lane / GS, l = lane % GS;
   const int W = blockDim.x >> 6;
   const int I = a.I;
 
@@ -593,17 +603,17 @@ __global__ void __launch_bounds__(256) nnls2_kernel(const NnlsArgs a) {
   const int ldw = r | 1;
   {
     const size_t tile = (size_t)a.rmax * (a.rmax | 1);
-    const size_t per_group = tile + 32 + 32 + 16;  // doubles (idx: 32 ints)
+    const size_t per_group = tile + GS + GS + GS / 2;  // doubles (idx: GS ints)
     double *shared_f = Hs + (size_t)a.rmax * a.rmax;
-    double *base = shared_f + tile + 32 + per_group * (size_t)(2 * wave + g);
+    double *base = shared_f + tile + 32 + per_group * (size_t)(NG * wave + g);
     gs.Lf = shared_f;
     gs.dgf = shared_f + tile;
     gs.fmask = 0;
     gs.Lw = base;
     gs.ldw = ldw;
     gs.cv = base + tile;
-    gs.xs = gs.cv + 32;
-    gs.idx = reinterpret_cast<int *>(gs.xs + 32);
+    gs.xs = gs.cv + GS;
+    gs.idx = reinterpret_cast<int *>(gs.xs + GS);
   }
   for (int e = tid; e < r * r; e += blockDim.x) {
     const int i = e % r, j = e / r;
@@ -620,16 +630,16 @@ __global__ void __launch_bounds__(256) nnls2_kernel(const NnlsArgs a) {
       cs = 0.0;
       for (int i = 0; i < r; ++i) cs += fabs(Hs[i + r * l]);
     }
-    tol = 10 * 2.2204e-16 * gmax(cs) * (double)r;
+    tol = 10 * 2.2204e-16 * gmax<GS>(cs) * (double)r;
   }
-  const unsigned rmask = (r >= 32) ? ~0u : ((1u << r) - 1u);
+  const unsigned rmask = (r >= 32) ? ~0u : ((1u << r) - 1u);  // (r <= GS: nnls_launch)
   {  // group 0 of wave 0 factors the full set into the shared tile
     __shared__ int s_full_ok2;
     if (wave == 0 && g == 0) {
       GroupScratch gf = gs;
       gf.Lw = const_cast<double *>(gs.Lf);
       double unused;
-      const bool ok = gsolve(Hs, r, gf, rmask, r, 0.0, l, 0, unused);
+      const bool ok = gsolve<GS>(Hs, r, gf, rmask, r, 0.0, l, 0, unused);
       if (ok) const_cast<double *>(gs.dgf)[l] = gf.dg;
       if (l == 0) s_full_ok2 = ok ? 1 : 0;
     }
@@ -648,33 +658,33 @@ __global__ void __launch_bounds__(256) nnls2_kernel(const NnlsArgs a) {
     const int row = rb;
     if (g == 0) {
 #else
-  for (int rb = row0 + 2 * wave; rb < row1; rb += 2 * W) {
+  for (int rb = row0 + NG * wave; rb < row1; rb += NG * W) {
     const int row = rb + g;
-    if (row < row1) {  // (the odd row of a chunk's tail leaves group 1 idle)
+    if (row < row1) {  // (a chunk's tail leaves the last groups idle)
 #endif
       const bool in = l < r;
       const double y = in ? (double)fac[row + (long long)I * l] : 0.0;
       unsigned act = (unsigned)actp[row] & rmask;
-      act &= ~gballot(in && y > 0.0, g);
+      act &= ~gballot<GS>(in && y > 0.0, g);
       double d = 0.0, sp = 0.0;
       int budget = NNLS_MAX_EXCHANGES(r);
       unsigned pas = ~act & rmask;
       if (pas) {  // warm start (update.cpp:93-121)
-        bool failed = !gsolve(Hs, r, gs, pas, __popc(pas), y, l, g, sp);
+        bool failed = !gsolve<GS>(Hs, r, gs, pas, __popc(pas), y, l, g, sp);
         if (!failed) {
           d = sp;
           for (;;) {
             const bool ip = (pas >> l) & 1u;
-            if (!(gmin(ip ? sp : DBL_MAX) <= tol)) break;
+            if (!(gmin<GS>(ip ? sp : DBL_MAX) <= tol)) break;
             const bool z = in && d <= tol;
             if (z) d = 0.0;
-            act |= gballot(z, g);
+            act |= gballot<GS>(z, g);
             pas = ~act & rmask;
             if (!pas) {  // ZeroPassiveSet
               failed = true;
               break;
             }
-            if (!gsolve(Hs, r, gs, pas, __popc(pas), y, l, g, sp)) {
+            if (!gsolve<GS>(Hs, r, gs, pas, __popc(pas), y, l, g, sp)) {
               failed = true;
               break;
             }
@@ -690,37 +700,37 @@ __global__ void __launch_bounds__(256) nnls2_kernel(const NnlsArgs a) {
           d = 0.0;
         }
       }
-      double w = gmultipliers(Hs, r, y, d, l, g);
+      double w = gmultipliers<GS>(Hs, r, y, d, l, g);
       for (;;) {  // main loop (update.cpp:126-167)
         if (!act || budget <= 0) break;
         const bool ia = (act >> l) & 1u;
-        const double wmax = gmax(ia ? w : -DBL_MAX);
+        const double wmax = gmax<GS>(ia ? w : -DBL_MAX);
         if (!(wmax > tol)) break;
-        const unsigned hit = gballot(ia && w == wmax, g);
+        const unsigned hit = gballot<GS>(ia && w == wmax, g);
         const int m = __ffs((int)hit) - 1;  // Tensor::max_id: the first of equal maxima
         const unsigned act_top = act;
         act &= ~(1u << m);
         pas = ~act & rmask;
-        if (!gsolve(Hs, r, gs, pas, __popc(pas), y, l, g, sp)) {
+        if (!gsolve<GS>(Hs, r, gs, pas, __popc(pas), y, l, g, sp)) {
           status |= 1;
           break;
         }
         bool stop = false;
         for (;;) {  // inner loop (update.cpp:136-157)
           const bool ip = (pas >> l) & 1u;
-          if (!(gmin(ip ? sp : DBL_MAX) <= tol)) break;
-          const double alpha = gmin((ip && sp <= tol) ? d / (d - sp) : DBL_MAX);
+          if (!(gmin<GS>(ip ? sp : DBL_MAX) <= tol)) break;
+          const double alpha = gmin<GS>((ip && sp <= tol) ? d / (d - sp) : DBL_MAX);
           if (in) d = d + alpha * (sp - d);
           const bool na = ip && fabs(d) < tol;
           if (na) d = 0.0;
-          act |= gballot(na, g);
+          act |= gballot<GS>(na, g);
           pas = ~act & rmask;
           if (!pas) {
             status |= 2;
             stop = true;
             break;
           }
-          if (!gsolve(Hs, r, gs, pas, __popc(pas), y, l, g, sp)) {
+          if (!gsolve<GS>(Hs, r, gs, pas, __popc(pas), y, l, g, sp)) {
             status |= 1;
             stop = true;
             break;
@@ -732,7 +742,7 @@ __global__ void __launch_bounds__(256) nnls2_kernel(const NnlsArgs a) {
         }
         if (stop) break;
         d = sp;
-        w = gmultipliers(Hs, r, y, d, l, g);
+        w = gmultipliers<GS>(Hs, r, y, d, l, g);
         if (act == act_top) {  // the pass reproduced its own starting state: the reference's loop never ends here
           status |= 2;
           break;
@@ -743,7 +753,7 @@ __global__ void __launch_bounds__(256) nnls2_kernel(const NnlsArgs a) {
         }
       }
       if (in) fac[row + (long long)I * l] = (T)d;
-      const double dot = gadd(in ? d * y : 0.0);
+      const double dot = gadd<GS>(in ? d * y : 0.0);
       if (l == 0) {
         actp[row] = (unsigned long long)act;
         rowdot[row] = dot;
@@ -753,10 +763,10 @@ __global__ void __launch_bounds__(256) nnls2_kernel(const NnlsArgs a) {
   if (status && l == 0) atomicOr(a.status, status);
 }
 
-size_t nnls2_lds_bytes(int rmax, int waves) {
+size_t nnls2_lds_bytes(int rmax, int waves, int gs) {
   const size_t tile = (size_t)rmax * (rmax | 1);
-  const size_t per_group = tile + 32 + 32 + 16;
-  return ((size_t)rmax * rmax + tile + 32 + per_group * 2 * waves) * sizeof(double);
+  const size_t per_group = tile + gs + gs + gs / 2;
+  return ((size_t)rmax * rmax + tile + 32 + per_group * (64 / gs) * waves) * sizeof(double);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -989,7 +999,8 @@ int nnls_huge_chunks(int I) { return std::max(1, std::min((I + 4 * NNLS_HWAVES -
 
 template <typename T>
 __global__ void __launch_bounds__(64 * NNLS_HWAVES) nnls_huge_kernel(const NnlsArgs a) {
-  const int k_model = blockIdx.x / a.chunks, chunk = blockIdx.x % a.chunks;
+  const int k_pos = blockIdx.x / a.chunks, chunk = blockIdx.x % a.chunks;
+  const int k_model = a.idx ? a.idx[k_pos] : k_pos;  // registry position (a class launch lists its own models)
   const int slot = a.slots[k_model];
   const int r = a.mt.rank[slot], col = a.mt.col[slot];
   if (r <= CALS_RMAX) return;  // nnls_kernel's share
@@ -1189,7 +1200,7 @@ __global__ void __launch_bounds__(64 * NNLS_HWAVES) nnls_huge_kernel(const NnlsA
   if (status && lane == 0) atomicOr(a.status, status);
 }
 
-int nnls_rank_class(int r) { return r <= 24 ? 0 : r <= 32 ? 1 : r <= 48 ? 2 : r <= CALS_RMAX ? 3 : 4; }
+int nnls_rank_class(int r) { return r <= 16 ? 0 : r <= 24 ? 1 : r <= 32 ? 2 : r <= 48 ? 3 : r <= CALS_RMAX ? 4 : 5; }
 
 size_t nnls_lds_bytes(int rmax, int waves) {
   const size_t per_wave = (size_t)rmax * (rmax | 1) + 64 + 64 + 32;
@@ -1214,12 +1225,19 @@ hipError_t nnls_launch(const NnlsArgs &a_in, hipStream_t st) {
   // are sized by the class's largest rank, so a single rank-48 model no longer leaves every workgroup of the
   // rank-1..20 models with 99 KB of LDS and one workgroup per CU (measured: +17 ms per sweep at C3's shape).
   // The workgroups of the other classes return at once.
-  static const int class_hi[4] = {24, 32, 48, CALS_RMAX};
-  for (int k = 0; k < 4; ++k) {
+  static const int class_hi[5] = {16, 24, 32, 48, CALS_RMAX};
+  for (int k = 0; k < 5; ++k) {
+    int n_models = a_in.n_slots;
+    a.idx = nullptr;
     if (a_in.rank_classes) {
       if (!(a_in.rank_classes & (1u << k))) continue;
       a.rlo = k ? class_hi[k - 1] + 1 : 1;
       a.rhi = class_hi[k];
+      if (a_in.cls_idx) {  // exactly this class's models: no workgroup is launched just to return
+        n_models = a_in.cls_off[k + 1] - a_in.cls_off[k];
+        a.idx = a_in.cls_idx + a_in.cls_off[k];
+        if (n_models <= 0) continue;
+      }
     } else {  // no class information: one launch sized by the largest rank
       if (k) break;
       a.rlo = 1;
@@ -1227,35 +1245,52 @@ hipError_t nnls_launch(const NnlsArgs &a_in, hipStream_t st) {
     }
     a.rmax = std::min(a.rhi, std::min(std::max(a_in.rmax, 1), CALS_RMAX));
     static const bool one_row = getenv("CALS_NNLS_ONE_ROW") != nullptr;  // A/B switch: one row per wave everywhere
-    const bool two_rows = a.rhi <= 32 && !one_row;                       // ranks <= 32: two rows per wavefront
+    // ranks <= 16: four rows per wavefront; 17..32: two; above (or without class information): one
+    const int gs = (one_row || !a_in.rank_classes) ? 64 : (a.rhi <= 16 ? 16 : (a.rhi <= 32 ? 32 : 64));
+    const bool two_rows = gs < 64;
     int waves = 4;
-    while (waves > 1 && (two_rows ? nnls2_lds_bytes(a.rmax, waves) : nnls_lds_bytes(a.rmax, waves)) > budget) --waves;
-    const size_t dyn = two_rows ? nnls2_lds_bytes(a.rmax, waves) : nnls_lds_bytes(a.rmax, waves);
+    while (waves > 1 && (two_rows ? nnls2_lds_bytes(a.rmax, waves, gs) : nnls_lds_bytes(a.rmax, waves)) > budget) --waves;
+    const size_t dyn = two_rows ? nnls2_lds_bytes(a.rmax, waves, gs) : nnls_lds_bytes(a.rmax, waves);
     // rows per workgroup: at least 4 per wave, enough workgroups to fill 256 CUs several times over
-    a.chunks = std::max(1, std::min((a.I + 4 * waves - 1) / (4 * waves), (4096 + a.n_slots - 1) / a.n_slots));
+    a.n_cls = n_models;
+    a.chunks = std::max(1, std::min((a.I + 4 * waves - 1) / (4 * waves), (4096 + n_models - 1) / n_models));
     static const int forced_chunks = getenv("CALS_NNLS_CHUNKS") ? atoi(getenv("CALS_NNLS_CHUNKS")) : 0;  // experiments
     if (forced_chunks > 0) a.chunks = std::min(forced_chunks, a.I);
-    const dim3 grid((unsigned)(a.n_slots * a.chunks)), block(64 * waves);
+    const dim3 grid((unsigned)(n_models * a.chunks)), block(64 * waves);
     if (two_rows) {
-      const void *fn2 = di ? reinterpret_cast<const void *>(&nnls2_kernel<float>)
-                           : reinterpret_cast<const void *>(&nnls2_kernel<double>);
-      static AttrOnce once2[2];
-      const hipError_t e2 = once2[di].ensure(
+      const int gi = gs == 16 ? 0 : 1;
+      const void *fn2 = di ? (gi ? reinterpret_cast<const void *>(&nnls2_kernel<float, 32>)
+                                 : reinterpret_cast<const void *>(&nnls2_kernel<float, 16>))
+                           : (gi ? reinterpret_cast<const void *>(&nnls2_kernel<double, 32>)
+                                 : reinterpret_cast<const void *>(&nnls2_kernel<double, 16>));
+      static AttrOnce once2[2][2];
+      const hipError_t e2 = once2[di][gi].ensure(
           [&] { return hipFuncSetAttribute(fn2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)budget); });
       if (e2 != hipSuccess) return e2;
-      if (di)
-        hipLaunchKernelGGL(nnls2_kernel<float>, grid, block, dyn, st, a);
+      if (di && gi)
+        hipLaunchKernelGGL((nnls2_kernel<float, 32>), grid, block, dyn, st, a);
+      else if (di)
+        hipLaunchKernelGGL((nnls2_kernel<float, 16>), grid, block, dyn, st, a);
+      else if (gi)
+        hipLaunchKernelGGL((nnls2_kernel<double, 32>), grid, block, dyn, st, a);
       else
-        hipLaunchKernelGGL(nnls2_kernel<double>, grid, block, dyn, st, a);
+        hipLaunchKernelGGL((nnls2_kernel<double, 16>), grid, block, dyn, st, a);
     } else if (di) {
       hipLaunchKernelGGL(nnls_kernel<float>, grid, block, dyn, st, a);
     } else {
       hipLaunchKernelGGL(nnls_kernel<double>, grid, block, dyn, st, a);
     }
   }
-  if (huge) {  // the models above CALS_RMAX; every other workgroup returns at once
+  if (huge) {  // the models above CALS_RMAX
+    int n_models = a_in.n_slots;
+    a.idx = nullptr;
+    if (a_in.rank_classes && a_in.cls_idx) {
+      n_models = a_in.cls_off[6] - a_in.cls_off[5];
+      a.idx = a_in.cls_idx + a_in.cls_off[5];
+    }
+    a.n_cls = n_models;
     a.chunks = nnls_huge_chunks(a.I);
-    const dim3 hgrid((unsigned)(a.n_slots * a.chunks)), hblock(64 * NNLS_HWAVES);
+    const dim3 hgrid((unsigned)(std::max(n_models, 1) * a.chunks)), hblock(64 * NNLS_HWAVES);
     if (di)
       hipLaunchKernelGGL(nnls_huge_kernel<float>, hgrid, hblock, 0, st, a);
     else
