@@ -198,6 +198,7 @@ struct NnlsArgs {
   unsigned rank_classes;  // bit k: a model of nnls_rank_class k is in flight (0: one launch sized by rmax)
   const int *cls_idx;  // registry positions sorted by nnls_rank_class (or nullptr: every launch walks all models and
   int cls_off[8];      // the other classes' workgroups return at once); class k = positions [cls_off[k], cls_off[k+1])
+  int seg_first[3], seg_rmax[3], seg_chunks[3];  // set by nnls_launch: the merged launch of the classes <= 16 / 24 / 32
   const int *idx;      // set by nnls_launch: this launch's models (registry positions), n_cls of them; nullptr = all
   int n_cls;
   int rlo, rhi;        // set by nnls_launch: the ranks this launch serves

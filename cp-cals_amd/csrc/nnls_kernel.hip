@@ -82,13 +82,20 @@ __device__ __forceinline__ unsigned long long uniform64(unsigned long long v) {
   return ((unsigned long long)hi << 32) | lo;
 }
 
+// Offset of row p of a strict lower triangle PACKED by rows (row p has p entries).  Packed, a rank-16 tile is 120
+// doubles instead of 16 x 17: the tiles are what bounds the workgroups per CU (3 -> 6 at C3's shape), and the kernel
+// is a chain of dependent steps that only more rows in flight hide (measured with padded LDS: 1 / 2 / 3 workgroups
+// per CU = 1.18 / 0.68 / 0.53 ms of NNLS per sweep; packed 0.45).  Row p of lane p starts at a triangular number: 32
+// consecutive ones hit 32 different 8-byte banks but for tri(0) = tri(1) (row 0 is empty).
+__device__ __forceinline__ int tri(int p) { return (p * (p - 1)) >> 1; }
+__host__ __device__ inline size_t tri_tile(int rmax) { return ((size_t)(rmax * (rmax - 1) / 2) + 1) & ~(size_t)1; }
+
 struct WaveScratch {
   unsigned n_solves = 0, n_factor = 0;  // CALS_DIAG statistics
   unsigned long long cached;  // passive set whose factor is in Lw / dg (0: none)
   double dg;                  // lane p: 1 / L[p][p] of that factor (the substitutions multiply: an IEEE f64
                               // division is ~25 instructions, and this kernel is issue bound)
-  double *Lw;   // strict lower triangle of the Cholesky factor of G[P,P], row p at Lw + p * ldw
-  int ldw;
+  double *Lw;   // strict lower triangle of the Cholesky factor of G[P,P], packed: row p at Lw + tri(p)
   int *idx;     // idx[p]: component of the p-th passive entry
   double *cv;   // compacted right-hand side
   double *xs;   // solution scattered back to component order
@@ -96,7 +103,7 @@ struct WaveScratch {
   // non-negative data starts all-passive in every sweep (y > 0 for every component), while its second solve -- about
   // every other row drops a component -- used to evict that factor from the wave's one-entry cache, so the next row
   // factored the full set again (tools/nnls_counts.py: 1.0 factorisations per row for 1.5 solves)
-  const double *Lf;   // strict lower triangle, row p at Lf + p * ldw
+  const double *Lf;   // strict lower triangle, row p at Lf + tri(p)
   const double *dgf;  // dgf[p] = 1 / L[p][p]
   unsigned long long fmask;  // the full set (0: not available)
 };
@@ -121,7 +128,7 @@ __device__ bool solve_passive(const double *Hs, int r, WaveScratch &ws, unsigned
   double t = valid ? ws.cv[p] : 0.0;
   double dg = 1.0;
   double *Lw = ws.Lw;
-  const int ldw = ws.ldw;
+  const int prow = tri(p);
   ws.n_solves++;
   const bool full = ws.fmask && pas == ws.fmask;
   const double *Ls = full ? ws.Lf : Lw;  // the factor the substitutions read
@@ -132,7 +139,7 @@ __device__ bool solve_passive(const double *Hs, int r, WaveScratch &ws, unsigned
       if (p == j)
         t = zj;
       else if (valid && p > j)
-        t -= Ls[p * ldw + j] * zj;
+        t -= Ls[prow + j] * zj;
     }
   } else {
   ws.cached = 0;
@@ -143,7 +150,7 @@ __device__ bool solve_passive(const double *Hs, int r, WaveScratch &ws, unsigned
     const int lrow = below ? p : j;  // the other lanes redo row j (unused)
     double ajj = Hs[ij + r * ij];
     double sv = Hs[(below ? myi : ij) + r * ij];
-    const double *rj = Lw + j * ldw, *ri = Lw + lrow * ldw;
+    const double *rj = Lw + tri(j), *ri = Lw + tri(lrow);
     int k = 0;
     for (; k + 4 <= j; k += 4) {  // four load pairs in flight; the subtractions stay in k order
       // (row j could also come from lane j by v_readlane instead of a broadcast LDS load: measured slower,
@@ -172,7 +179,7 @@ __device__ bool solve_passive(const double *Hs, int r, WaveScratch &ws, unsigned
     rl = rl * fma(-0.5 * ajj * rl, rl, 1.5);
     rl = rl * fma(-0.5 * ajj * rl, rl, 1.5);
     const double lij = sv * rl;
-    if (below) Lw[p * ldw + j] = lij;
+    if (below) Lw[prow + j] = lij;
     const double zj = bcast(t, j) * rl;  // forward substitution, column by column
     if (p == j) {
       t = zj;
@@ -190,7 +197,7 @@ __device__ bool solve_passive(const double *Hs, int r, WaveScratch &ws, unsigned
     if (p == j)
       t = xj;
     else if (valid && p < j)
-      t -= Ls[j * ldw + p] * xj;
+      t -= Ls[tri(j) + p] * xj;
   }
   if (valid) ws.xs[myi] = t;
   WAVE_SYNC();
@@ -227,16 +234,15 @@ __global__ void __launch_bounds__(256) nnls_kernel(const NnlsArgs a) {
   ws.cached = 0;
   ws.dg = 1.0;
   {
-    const int ldw = r | 1;
-    const size_t per_wave = (size_t)a.rmax * (a.rmax | 1) + 64 + 64 + 32;  // doubles (idx: 64 ints)
+    const size_t tile = tri_tile(a.rmax);
+    const size_t per_wave = tile + 64 + 64 + 32;  // doubles (idx: 64 ints)
     double *shared_f = Hs + (size_t)a.rmax * a.rmax;  // the workgroup's full-set factor + its diagonal
-    double *base = shared_f + (size_t)a.rmax * (a.rmax | 1) + 64 + per_wave * wave;
+    double *base = shared_f + tile + 64 + per_wave * wave;
     ws.Lf = shared_f;
-    ws.dgf = shared_f + (size_t)a.rmax * (a.rmax | 1);
+    ws.dgf = shared_f + tile;
     ws.fmask = 0;
     ws.Lw = base;
-    ws.ldw = ldw;
-    ws.cv = base + (size_t)a.rmax * (a.rmax | 1);
+    ws.cv = base + tile;
     ws.xs = ws.cv + 64;
     ws.idx = reinterpret_cast<int *>(ws.xs + 64);
   }
@@ -466,8 +472,7 @@ __device__ __forceinline__ int gmax_int(int n) {
 struct GroupScratch {
   unsigned cached;  // passive set whose factor is in Lw / dg (0: none)
   double dg;        // lane p of the group: 1 / L[p][p] of that factor
-  double *Lw;       // the group's tile: strict lower triangle, row p at Lw + p * ldw
-  int ldw;
+  double *Lw;       // the group's tile: the strict lower triangle PACKED by rows, row p (p entries) at Lw + tri(p)
   int *idx;
   double *cv, *xs;
   const double *Lf, *dgf;  // the workgroup's factor of the full set
@@ -490,7 +495,7 @@ __device__ bool gsolve(const double *Hs, int r, GroupScratch &gs, unsigned pas, 
   double t = valid ? gs.cv[p] : 0.0;
   double dg = 1.0;
   double *Lw = gs.Lw;
-  const int ldw = gs.ldw;
+  const int prow = tri(p);
   const bool full = gs.fmask && pas == gs.fmask;
   const double *Ls = full ? gs.Lf : Lw;
   bool ok = true;
@@ -501,7 +506,7 @@ __device__ bool gsolve(const double *Hs, int r, GroupScratch &gs, unsigned pas, 
       if (p == j)
         t = zj;
       else if (valid && p > j)
-        t -= Ls[p * ldw + j] * zj;
+        t -= Ls[prow + j] * zj;
     }
   } else {
     gs.cached = 0;
@@ -511,7 +516,7 @@ __device__ bool gsolve(const double *Hs, int r, GroupScratch &gs, unsigned pas, 
       const int lrow = below ? p : j;
       double ajj = Hs[ij + r * ij];
       double sv = Hs[(below ? myi : ij) + r * ij];
-      const double *rj = Lw + j * ldw, *ri = Lw + lrow * ldw;
+      const double *rj = Lw + tri(j), *ri = Lw + tri(lrow);
       int k = 0;
       for (; k + 4 <= j; k += 4) {
         const double l0 = rj[k], l1 = rj[k + 1], l2 = rj[k + 2], l3 = rj[k + 3];
@@ -538,7 +543,7 @@ __device__ bool gsolve(const double *Hs, int r, GroupScratch &gs, unsigned pas, 
       rl = rl * fma(-0.5 * ajj * rl, rl, 1.5);
       rl = rl * fma(-0.5 * ajj * rl, rl, 1.5);
       const double lij = sv * rl;
-      if (below) Lw[p * ldw + j] = lij;
+      if (below) Lw[prow + j] = lij;
       const double zj = gbcast<GS>(t, j, g) * rl;
       if (p == j) {
         t = zj;
@@ -562,7 +567,7 @@ __device__ bool gsolve(const double *Hs, int r, GroupScratch &gs, unsigned pas, 
         if (p == j)
           t = xj;
         else if (valid && p < j)
-          t -= Ls[j * ldw + p] * xj;
+          t -= Ls[tri(j) + p] * xj;
       }
     }
     if (valid) gs.xs[myi] = t;
@@ -583,14 +588,15 @@ __device__ __forceinline__ double gmultipliers(const double *Hs, int r, double y
 
 }  // namespace
 
+// One rank class's share of the merged launch (nnls2m_kernel): block `blk` of the class's n_models * chunks, its
+// models listed in idx (registry positions), LDS tiles sized for rmax.
 template <typename T, int GS>
-__global__ void __launch_bounds__(256) nnls2_kernel(const NnlsArgs a) {
+__device__ __forceinline__ void nnls2_body(const NnlsArgs &a, int blk, int rmax_c, int chunks_c, const int *idx) {
   constexpr int NG = 64 / GS;  // rows per wavefront
-  const int k_pos = blockIdx.x / a.chunks, chunk = blockIdx.x % a.chunks;
-  const int k_model = a.idx ? a.idx[k_pos] : k_pos;  // registry position (a class launch lists its own models)
+  const int k_pos = blk / chunks_c, chunk = blk % chunks_c;
+  const int k_model = idx[k_pos];
   const int slot = a.slots[k_model];
   const int r = a.mt.rank[slot], col = a.mt.col[slot];
-  if (r < a.rlo || r > a.rhi) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane / GS, l = lane % GS;
   const int W = blockDim.x >> 6;
@@ -600,17 +606,15 @@ __global__ void __launch_bounds__(256) nnls2_kernel(const NnlsArgs a) {
   GroupScratch gs;
   gs.cached = 0;
   gs.dg = 1.0;
-  const int ldw = r | 1;
   {
-    const size_t tile = (size_t)a.rmax * (a.rmax | 1);
+    const size_t tile = tri_tile(rmax_c);
     const size_t per_group = tile + GS + GS + GS / 2;  // doubles (idx: GS ints)
-    double *shared_f = Hs + (size_t)a.rmax * a.rmax;
+    double *shared_f = Hs + (size_t)rmax_c * rmax_c;
     double *base = shared_f + tile + 32 + per_group * (size_t)(NG * wave + g);
     gs.Lf = shared_f;
     gs.dgf = shared_f + tile;
     gs.fmask = 0;
     gs.Lw = base;
-    gs.ldw = ldw;
     gs.cv = base + tile;
     gs.xs = gs.cv + GS;
     gs.idx = reinterpret_cast<int *>(gs.xs + GS);
@@ -649,7 +653,7 @@ __global__ void __launch_bounds__(256) nnls2_kernel(const NnlsArgs a) {
   T *fac = static_cast<T *>(a.factor) + (long long)I * col;
   unsigned long long *actp = a.act + (long long)I * col;
   double *rowdot = a.rowdot + (long long)I * k_model;
-  const int rows_per = (I + a.chunks - 1) / a.chunks;
+  const int rows_per = (I + chunks_c - 1) / chunks_c;
   const int row0 = chunk * rows_per, row1 = min(I, row0 + rows_per);
   int status = 0;
 
@@ -763,8 +767,23 @@ __global__ void __launch_bounds__(256) nnls2_kernel(const NnlsArgs a) {
   if (status && l == 0) atomicOr(a.status, status);
 }
 
+// Ranks <= 32 in ONE launch: the classes <= 16 (four rows per wave), <= 24 and <= 32 (two rows, LDS tiles of their own
+// size) as consecutive block ranges (NnlsArgs::seg_*).  As separate launches on the one stream the classes ran one
+// after the other -- 98 + 94 us per mode at C3's shape for 205 + 51 models -- although each of them alone is bound by
+// the latency of its rows' dependent steps, not by the chip.
+template <typename T>
+__global__ void __launch_bounds__(256) nnls2m_kernel(const NnlsArgs a) {
+  const int b = blockIdx.x;
+  if (b < a.seg_first[1])
+    nnls2_body<T, 16>(a, b, a.seg_rmax[0], a.seg_chunks[0], a.cls_idx + a.cls_off[0]);
+  else if (b < a.seg_first[2])
+    nnls2_body<T, 32>(a, b - a.seg_first[1], a.seg_rmax[1], a.seg_chunks[1], a.cls_idx + a.cls_off[1]);
+  else
+    nnls2_body<T, 32>(a, b - a.seg_first[2], a.seg_rmax[2], a.seg_chunks[2], a.cls_idx + a.cls_off[2]);
+}
+
 size_t nnls2_lds_bytes(int rmax, int waves, int gs) {
-  const size_t tile = (size_t)rmax * (rmax | 1);
+  const size_t tile = tri_tile(rmax);
   const size_t per_group = tile + gs + gs + gs / 2;
   return ((size_t)rmax * rmax + tile + 32 + per_group * (64 / gs) * waves) * sizeof(double);
 }
@@ -1203,8 +1222,8 @@ __global__ void __launch_bounds__(64 * NNLS_HWAVES) nnls_huge_kernel(const NnlsA
 int nnls_rank_class(int r) { return r <= 16 ? 0 : r <= 24 ? 1 : r <= 32 ? 2 : r <= 48 ? 3 : r <= CALS_RMAX ? 4 : 5; }
 
 size_t nnls_lds_bytes(int rmax, int waves) {
-  const size_t per_wave = (size_t)rmax * (rmax | 1) + 64 + 64 + 32;
-  return ((size_t)rmax * rmax + (size_t)rmax * (rmax | 1) + 64 + per_wave * waves) * sizeof(double);
+  const size_t per_wave = tri_tile(rmax) + 64 + 64 + 32;
+  return ((size_t)rmax * rmax + tri_tile(rmax) + 64 + per_wave * waves) * sizeof(double);
 }
 
 hipError_t nnls_launch(const NnlsArgs &a_in, hipStream_t st) {
@@ -1226,14 +1245,53 @@ hipError_t nnls_launch(const NnlsArgs &a_in, hipStream_t st) {
   // rank-1..20 models with 99 KB of LDS and one workgroup per CU (measured: +17 ms per sweep at C3's shape).
   // The workgroups of the other classes return at once.
   static const int class_hi[5] = {16, 24, 32, 48, CALS_RMAX};
-  for (int k = 0; k < 5; ++k) {
+  static const bool one_row = getenv("CALS_NNLS_ONE_ROW") != nullptr;  // A/B switch: one row per wave everywhere
+  static const int forced_chunks = getenv("CALS_NNLS_CHUNKS") ? atoi(getenv("CALS_NNLS_CHUNKS")) : 0;  // experiments
+  int k_first = 0;
+  if (a_in.rank_classes && a_in.cls_idx && !one_row && (a_in.rank_classes & 7u)) {
+    // ---- ranks <= 32: several rows per wavefront, the three classes merged into one launch ----
+    const int waves = 4;
+    size_t dyn = 0;
+    int blocks = 0;
+    for (int k = 0; k < 3; ++k) {
+      const int n = a_in.cls_off[k + 1] - a_in.cls_off[k];
+      a.seg_first[k] = blocks;
+      a.seg_rmax[k] = std::min(class_hi[k], std::min(std::max(a_in.rmax, 1), CALS_RMAX));
+      a.seg_chunks[k] = 1;
+      if (n <= 0) continue;
+      int chunks = std::max(1, std::min((a.I + 4 * waves - 1) / (4 * waves), (4096 + n - 1) / n));
+      if (forced_chunks > 0) chunks = std::min(forced_chunks, a.I);
+      a.seg_chunks[k] = chunks;
+      blocks += n * chunks;
+      dyn = std::max(dyn, nnls2_lds_bytes(a.seg_rmax[k], waves, k == 0 ? 16 : 32));
+    }
+    const void *fn2 = di ? reinterpret_cast<const void *>(&nnls2m_kernel<float>)
+                         : reinterpret_cast<const void *>(&nnls2m_kernel<double>);
+    static AttrOnce once2[2];
+    const hipError_t e2 = once2[di].ensure(
+        [&] { return hipFuncSetAttribute(fn2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)budget); });
+    if (e2 != hipSuccess) return e2;
+    if (dyn > budget) return hipErrorInvalidValue;
+    const dim3 grid((unsigned)blocks), block(64 * waves);
+    if (di)
+      hipLaunchKernelGGL(nnls2m_kernel<float>, grid, block, dyn, st, a);
+    else
+      hipLaunchKernelGGL(nnls2m_kernel<double>, grid, block, dyn, st, a);
+    k_first = 3;
+  }
+  // One launch per remaining rank class in flight (a_in.rank_classes, bit k = class k of nnls_rank_class), one row per
+  // wavefront: the LDS tiles are sized by the class's largest rank, so a single rank-48 model does not leave every
+  // workgroup of the rank-1..20 models with 99 KB of LDS and one workgroup per CU (measured: +17 ms per sweep at C3's
+  // shape).  With class lists (cls_idx) a launch's workgroups are exactly its models; without, the other classes'
+  // workgroups return at once.
+  for (int k = k_first; k < 5; ++k) {
     int n_models = a_in.n_slots;
     a.idx = nullptr;
     if (a_in.rank_classes) {
       if (!(a_in.rank_classes & (1u << k))) continue;
       a.rlo = k ? class_hi[k - 1] + 1 : 1;
       a.rhi = class_hi[k];
-      if (a_in.cls_idx) {  // exactly this class's models: no workgroup is launched just to return
+      if (a_in.cls_idx) {
         n_models = a_in.cls_off[k + 1] - a_in.cls_off[k];
         a.idx = a_in.cls_idx + a_in.cls_off[k];
         if (n_models <= 0) continue;
@@ -1244,42 +1302,18 @@ hipError_t nnls_launch(const NnlsArgs &a_in, hipStream_t st) {
       a.rhi = CALS_RMAX;
     }
     a.rmax = std::min(a.rhi, std::min(std::max(a_in.rmax, 1), CALS_RMAX));
-    static const bool one_row = getenv("CALS_NNLS_ONE_ROW") != nullptr;  // A/B switch: one row per wave everywhere
-    // ranks <= 16: four rows per wavefront; 17..32: two; above (or without class information): one
-    const int gs = (one_row || !a_in.rank_classes) ? 64 : (a.rhi <= 16 ? 16 : (a.rhi <= 32 ? 32 : 64));
-    const bool two_rows = gs < 64;
     int waves = 4;
-    while (waves > 1 && (two_rows ? nnls2_lds_bytes(a.rmax, waves, gs) : nnls_lds_bytes(a.rmax, waves)) > budget) --waves;
-    const size_t dyn = two_rows ? nnls2_lds_bytes(a.rmax, waves, gs) : nnls_lds_bytes(a.rmax, waves);
+    while (waves > 1 && nnls_lds_bytes(a.rmax, waves) > budget) --waves;
+    const size_t dyn = nnls_lds_bytes(a.rmax, waves);
     // rows per workgroup: at least 4 per wave, enough workgroups to fill 256 CUs several times over
     a.n_cls = n_models;
     a.chunks = std::max(1, std::min((a.I + 4 * waves - 1) / (4 * waves), (4096 + n_models - 1) / n_models));
-    static const int forced_chunks = getenv("CALS_NNLS_CHUNKS") ? atoi(getenv("CALS_NNLS_CHUNKS")) : 0;  // experiments
     if (forced_chunks > 0) a.chunks = std::min(forced_chunks, a.I);
     const dim3 grid((unsigned)(n_models * a.chunks)), block(64 * waves);
-    if (two_rows) {
-      const int gi = gs == 16 ? 0 : 1;
-      const void *fn2 = di ? (gi ? reinterpret_cast<const void *>(&nnls2_kernel<float, 32>)
-                                 : reinterpret_cast<const void *>(&nnls2_kernel<float, 16>))
-                           : (gi ? reinterpret_cast<const void *>(&nnls2_kernel<double, 32>)
-                                 : reinterpret_cast<const void *>(&nnls2_kernel<double, 16>));
-      static AttrOnce once2[2][2];
-      const hipError_t e2 = once2[di][gi].ensure(
-          [&] { return hipFuncSetAttribute(fn2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)budget); });
-      if (e2 != hipSuccess) return e2;
-      if (di && gi)
-        hipLaunchKernelGGL((nnls2_kernel<float, 32>), grid, block, dyn, st, a);
-      else if (di)
-        hipLaunchKernelGGL((nnls2_kernel<float, 16>), grid, block, dyn, st, a);
-      else if (gi)
-        hipLaunchKernelGGL((nnls2_kernel<double, 32>), grid, block, dyn, st, a);
-      else
-        hipLaunchKernelGGL((nnls2_kernel<double, 16>), grid, block, dyn, st, a);
-    } else if (di) {
+    if (di)
       hipLaunchKernelGGL(nnls_kernel<float>, grid, block, dyn, st, a);
-    } else {
+    else
       hipLaunchKernelGGL(nnls_kernel<double>, grid, block, dyn, st, a);
-    }
   }
   if (huge) {  // the models above CALS_RMAX
     int n_models = a_in.n_slots;
