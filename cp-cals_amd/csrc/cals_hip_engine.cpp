@@ -156,8 +156,10 @@ struct cals_hip_engine {
   int out_wpe = 2;
   void *partial = nullptr;
   size_t partial_elems = 0;
-  double *hscratch = nullptr;  // models of rank > CALS_RMAX: H / L blocks of update_body_huge
+  double *hscratch = nullptr;  // models of rank > CALS_RMAX: H / L blocks of the huge_* update launches
   size_t hscratch_blocks = 0;
+  double *hrowdot = nullptr;   // ... and their rows' <z, z> (unconstrained update), [n_huge][I]
+  size_t hrowdot_len = 0;
   double *nnls_hscratch = nullptr;  // ... and the blocks of nnls_huge_kernel
   size_t nnls_hblocks = 0;
   int *d_hcounter = nullptr;
@@ -836,10 +838,10 @@ int sweep_once(cals_hip_engine *e, bool evict_enabled, bool defer_changed = fals
   int rank_max = 1;  // sizes the update kernel's LDS panel
   size_t n_huge = 0;  // models above CALS_RMAX: the update needs a global H / L block each
   unsigned rank_classes = 0;  // which LDS size classes of the NNLS kernel are in flight
-  int upd_classes = 0;        // update kernels to launch: bit 0 = ranks <= CALS_RFAST, bit 1 = above
+  int upd_classes = 0;        // update kernels to launch: bit 0 = ranks <= CALS_RFAST, bit 1 = 33..CALS_RMAX, bit 2 = above
   for (auto t : e->registry) {
     rank_max = std::max(rank_max, (int)e->models[t].rank);
-    upd_classes |= (e->models[t].rank <= CALS_RFAST) ? 1 : 2;
+    upd_classes |= (e->models[t].rank <= CALS_RFAST) ? 1 : (e->models[t].rank <= CALS_RMAX) ? 2 : 4;
     if (e->models[t].rank > CALS_RMAX) n_huge++;
     rank_classes |= 1u << nnls_rank_class((int)e->models[t].rank);
   }
@@ -854,6 +856,18 @@ int sweep_once(cals_hip_engine *e, bool evict_enabled, bool defer_changed = fals
         e->nnls_hblocks = 0;
         HIPCHK(hipMalloc((void **)&e->nnls_hscratch, need * nnls_huge_block_doubles() * sizeof(double)));
         e->nnls_hblocks = need;
+      }
+    }
+    if (e->prm.update_method != 1) {  // huge_solve_kernel's <z, z> per row, [n_huge][I]
+      int64_t imax = 1;
+      for (int n = 0; n < e->n_modes; n++) imax = std::max(imax, e->modes[n]);
+      const size_t need = n_huge * (size_t)imax;
+      if (need > e->hrowdot_len) {
+        if (e->hrowdot) HIPCHK(hipFree(e->hrowdot));
+        e->hrowdot = nullptr;
+        e->hrowdot_len = 0;
+        HIPCHK(hipMalloc((void **)&e->hrowdot, (need + need / 2) * sizeof(double)));
+        e->hrowdot_len = need + need / 2;
       }
     }
     if (e->prm.line_search && e->prm.line_search_method != 0) n_huge *= 2;  // H and one Gramian at a time
@@ -922,7 +936,9 @@ int sweep_once(cals_hip_engine *e, bool evict_enabled, bool defer_changed = fals
     u.dbg_trace = e->dbg_trace ? e->dbg_trace + 16 * 2048 - 64 : nullptr;  // last 64 entries of the trace
     u.hscratch = e->hscratch;
     u.hcounter = e->d_hcounter;
-    if (n_huge) HIPCHK(hipMemsetAsync(e->d_hcounter, 0, sizeof(int), e->stream));
+    u.huge_idx = e->d_cls_idx + e->cls_off[5];  // the models above CALS_RMAX (class 5 of nnls_rank_class)
+    u.n_huge = e->cls_off[6] - e->cls_off[5];
+    u.hrowdot = e->hrowdot;
     const int pk = prof_begin(e, 1, 0, LOG_UPDATE);
     // The update bodies for ranks <= CALS_RFAST sum the split-K partial tiles of their model's columns themselves
     // (UpdateArgs::partial): no reduce launch, no round trip of G through the factor buffer.  The NNLS kernel and
@@ -931,7 +947,7 @@ int sweep_once(cals_hip_engine *e, bool evict_enabled, bool defer_changed = fals
     // the whole chip (C2, pT = 51: 4300 it/s folded against 5870; C3, pT = 12: equal; C4, pT = 6: +0.7 %).
     static const int fold_max_t = getenv("CALS_UPDATE_FOLD_MAX_T") ? atoi(getenv("CALS_UPDATE_FOLD_MAX_T")) : 8;
     static const bool no_pack = getenv("CALS_UPDATE_NO_PACK") != nullptr;  // A/B switch
-    const bool fold = !g_in_place && e->prm.update_method == 0 && !(upd_classes & 2) && g.T <= fold_max_t;
+    const bool fold = !g_in_place && e->prm.update_method == 0 && !(upd_classes & 6) && g.T <= fold_max_t;
     if (fold) {
       u.partial = e->partial;
       u.pT = g.T;
@@ -944,7 +960,7 @@ int sweep_once(cals_hip_engine *e, bool evict_enabled, bool defer_changed = fals
     // is a TTM whose inner mode is this one -- i.e. no T is pending for it (sweep order 0 1 2 0 1 2 ...).  A line
     // search between this sweep's last mode and the next sweep's mode 0 rewrites factors: pt_invalidate below.
     bool packs = false;
-    if (e->tree.on && e->n_modes == 3 && !(upd_classes & 2) && !no_pack) {
+    if (e->tree.on && e->n_modes == 3 && !(upd_classes & 6) && !no_pack) {
       const int nxt = (n + 1) % 3;
       if (e->tree.pair[nxt].on && e->tree.t_second != nxt) {
         u.pt = e->tree.Pt;
@@ -979,8 +995,8 @@ int sweep_once(cals_hip_engine *e, bool evict_enabled, bool defer_changed = fals
       q.dbg_counts = e->dbg_trace ? e->dbg_trace + 8 * 2048 + 1024 : nullptr;  // CALS_DIAG + CALS_TTM_TRACE: row / solve counters
       q.hscratch = e->nnls_hscratch;
       q.hcounter = e->d_hcounter;
+      if (n_huge) HIPCHK(hipMemsetAsync(e->d_hcounter, 0, sizeof(int), e->stream));  // nnls_huge_kernel's blocks
       HIPCHK(nnls_launch(q, e->stream));
-      if (n_huge) HIPCHK(hipMemsetAsync(e->d_hcounter, 0, sizeof(int), e->stream));
       u.rowdot = e->rowdot;
     }
     HIPCHK(update_launch(u, rank_max, e->stream, upd_classes));
@@ -1865,6 +1881,7 @@ int cals_hip_destroy(cals_hip_engine *e) {
   if (e->ev_out) (void)hipEventDestroy(e->ev_out);
   fr(e->partial);
   fr(e->hscratch);
+  fr(e->hrowdot);
   fr(e->nnls_hscratch);
   fr(e->d_hcounter);
   fr(e->tree.Tbuf);

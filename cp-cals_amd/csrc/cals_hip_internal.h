@@ -175,8 +175,15 @@ struct UpdateArgs {
   // on their way out -- no pack_pt launch in front of that TTM.
   void *pt;
   int ptAp;
+  // Models above CALS_RMAX (ranks 65..CALS_GLD): their registry positions (n_huge of them; the engine's class list),
+  // the H / L block of model h is block h of hscratch.  Their update is a pipeline of launches (update_launch).
+  // hrowdot: [n_huge][I], written by the solve launch when rowdot is nullptr (unconstrained update).
+  const int *huge_idx;
+  int n_huge;
+  double *hrowdot;
 };
-// classes: bit 0 = models of rank <= CALS_RFAST in flight, bit 1 = models above it (0 = unknown: both kernels)
+// classes: bit 0 = models of rank <= CALS_RFAST in flight, bit 1 = ranks 33..CALS_RMAX, bit 2 = above (0 = unknown:
+// every kernel)
 hipError_t update_launch(const UpdateArgs &a, int rmax_needed, hipStream_t st, int classes = 0);
 
 // update::update_factor_non_negative_constrained for one mode (nnls_kernel.hip)

@@ -1418,13 +1418,435 @@ __global__ void __launch_bounds__(UPD_THREADS, 1) update_huge_kernel(const Updat
   __shared__ UpdShared sh;
   const int slot = a.slots[blockIdx.x];
   const int r = a.mt.rank[slot];
-  if (r <= CALS_RFAST) return;
-  if (r > CALS_RMAX)
-    update_body_huge<T, false>(a_ptr, slot, r, sh);
-  else
-    update_body_huge<T, true>(a_ptr, slot, r, sh);
+  if (r <= CALS_RFAST || r > CALS_RMAX) return;  // above CALS_RMAX: the huge_* launches (update_launch)
+  update_body_huge<T, true>(a_ptr, slot, r, sh);
 }
 #undef UPD_DISPATCH
+
+// ---------------------------------------------------------------------------------------------
+// Ranks 65..CALS_GLD (round 3): the update of such a model as a PIPELINE OF LAUNCHES, each spread over as many
+// workgroups as its step has independent pieces.  update_body_huge<T, false> ran the whole update on ONE workgroup:
+// 2.6 ms per mode for a rank-256 model at C3's shape (Hadamard 0.22, Cholesky 0.42, row solves 1.23 -- 300 rows on
+// 256 threads, 131 k dependent FMAs each --, scales 0.18, Gramian 0.57), all of it on the critical path of a sweep.
+//   huge_hadamard_kernel  H = hadamard of the other modes' Gramians, identity padded   wave = column
+//   huge_potrf_kernel     dpotf2 in panels of 16 columns (the code of the one-workgroup body)   one workgroup
+//   huge_solve_kernel     B := B inv(L^T) inv(L) on the matrix cores                   wave = 16 rows
+//   huge_scale_kernel     column scales + normalisation                                wave = column
+//   huge_gram_kernel      update_gramian                                               workgroup = one 16 x 16 tile pair
+//   huge_error_kernel     fast error + end-of-sweep rule (last mode only)              one workgroup
+// Model h of the class (UpdateArgs::huge_idx) owns block h of hscratch -- no counter.  After the NNLS update
+// (a.rowdot) the factor and the solve launches are skipped, as the `solved` path of the other bodies.
+// ---------------------------------------------------------------------------------------------
+#define HUGE_PROLOGUE()                                                      \
+  UpdArgsRef a = *upd_kernargs();                                            \
+  const int h = blockIdx.y;                                                  \
+  const int k_model = a.huge_idx[h];                                         \
+  const int slot = a.slots[k_model];                                         \
+  const int r = a.mt.rank[slot], col = a.mt.col[slot];                       \
+  const int rp = (r + 15) & ~15;                                             \
+  const int I = a.I;                                                         \
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;             \
+  (void)k_model; (void)rp; (void)I; (void)lane; (void)wave; (void)col
+
+__global__ void __launch_bounds__(256) huge_hadamard_kernel(const UpdateArgs a_by_value) {
+  (void)a_by_value;
+  HUGE_PROLOGUE();
+  double *__restrict__ H = a.hscratch + (long long)h * CALS_GLD * CALS_GLD;
+  for (int j = blockIdx.x * 4 + wave; j < rp; j += gridDim.x * 4)
+    for (int i = lane; i < rp; i += 64) {
+      double v = (i == j) ? 1.0 : 0.0;  // identity padding: L comes out as diag(L_r, I)
+      if (i < r && j < r) {
+        v = 1.0;
+        for (int m = 0; m < a.n_modes; ++m)
+          if (m != a.mode) v *= a.gram[m][i + CALS_GLD * (long long)(col + j)];
+      }
+      H[i + CALS_GLD * j] = v;
+    }
+}
+
+// dpotf2 in panels of 16 columns, thread = row (rp <= 256 rows, the padding rows are identity rows):
+//   S[i][c] = H[i][jb + c] - sum_{k < jb} L[i][k] L[jb + c][k]   in registers, four k in flight;
+//   the 16 x 16 diagonal block goes to LDS, where wave 0 factors it column by column (right-looking inside
+//   the block); every row below it then applies the block's columns to its own 16 values.
+// Every entry sees the subtractions of dpotf2 in dpotf2's order (k ascending), so the factor is the unblocked
+// one bit for bit; a non-positive pivot stops at its column with the earlier columns final and the rest of H
+// untouched, exactly the state the column-by-column form leaves (update.cpp:183-185 only logs info).  Every
+// L[i][j] is also written TRANSPOSED into the upper triangle of the block, so that both substitutions of the
+// solve read 16 consecutive doubles per step.
+__global__ void __launch_bounds__(256) huge_potrf_kernel(const UpdateArgs a_by_value) {
+  (void)a_by_value;
+  HUGE_PROLOGUE();
+  constexpr int XB = 16, LD = CALS_GLD;
+  typedef double v2d __attribute__((ext_vector_type(2)));
+  double *__restrict__ H = a.hscratch + (long long)h * CALS_GLD * CALS_GLD;
+  __shared__ double s_dblk[XB][XB + 1];
+  __shared__ double s_piv;
+  __shared__ int s_info, s_fail;
+  if (tid == 0) s_info = 0;
+  __syncthreads();
+  for (int jb = 0; jb < rp; jb += XB) {
+    const int i = tid;
+    const bool act = i >= jb && i < rp;
+    double sacc[XB];
+#pragma unroll
+    for (int c = 0; c < XB; ++c) sacc[c] = 0.0;
+    if (act) {
+#pragma unroll
+      for (int c = 0; c < XB; ++c) sacc[c] = H[i + (long long)LD * (jb + c)];
+      for (int k = 0; k < jb; k += 4) {
+        double own[4];
+        v2d pan[4][XB / 2];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          own[u] = H[i + (long long)LD * (k + u)];
+          const v2d *hp = reinterpret_cast<const v2d *>(H + jb + (long long)LD * (k + u));  // L[jb + c][k + u]
+#pragma unroll
+          for (int c = 0; c < XB / 2; ++c) pan[u][c] = hp[c];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+          for (int c = 0; c < XB; c += 2) {
+            sacc[c] -= own[u] * pan[u][c >> 1][0];
+            sacc[c + 1] -= own[u] * pan[u][c >> 1][1];
+          }
+        }
+      }
+      if (i < jb + XB) {
+#pragma unroll
+        for (int c = 0; c < XB; ++c) s_dblk[i - jb][c] = sacc[c];
+      }
+    }
+    if (tid == 0) s_fail = XB;
+    __syncthreads();
+    if (wave == 0) {
+      // lane = row of the block, the row in registers; column c: the pivot and the finished column travel by
+      // v_readlane.  Right-looking inside the block: entry (row, c2) sees the subtractions k = jb, jb + 1, ...
+      // in dpotf2's order.  Lanes >= 16 compute on zeros.
+      double rv[XB];
+#pragma unroll
+      for (int c = 0; c < XB; ++c) rv[c] = (lane < XB) ? s_dblk[lane][c] : 0.0;
+      int fail = XB;
+      double fpiv = 0.0;
+#pragma unroll
+      for (int c = 0; c < XB; ++c) {
+        if (fail == XB) {
+          const double piv = lane_bcast(rv[c], c);
+          if (!(piv > 0.0)) {
+            fail = c;
+            fpiv = piv;
+          } else {
+            const double lcc = sqrt(piv);
+            const double l = (lane == c) ? lcc : rv[c] / lcc;
+            rv[c] = l;
+#pragma unroll
+            for (int c2 = c + 1; c2 < XB; ++c2) {
+              const double lc2 = lane_bcast(l, c2);  // L[c2][c]
+              if (lane > c) rv[c2] -= l * lc2;
+            }
+          }
+        }
+      }
+      if (lane < XB) {
+#pragma unroll
+        for (int c = 0; c < XB; ++c) s_dblk[lane][c] = rv[c];
+      }
+      if (lane == 0 && fail < XB) {
+        s_fail = fail;
+        s_piv = fpiv;
+      }
+    }
+    __syncthreads();
+    const int ncol = s_fail;  // columns of this panel that are final
+    if (act) {
+      if (i >= jb + XB) {  // below the block: L[i][jb + c] = (S[i][c] - sum_{c' < c} L[i][jb + c'] L[jb + c][jb + c']) / L_cc
+#pragma unroll
+        for (int c = 0; c < XB; ++c) {
+          if (c < ncol) {
+            const double l = sacc[c] / s_dblk[c][c];
+            sacc[c] = l;
+#pragma unroll
+            for (int c2 = c + 1; c2 < XB; ++c2) sacc[c2] -= l * s_dblk[c2][c];
+          }
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < XB; ++c) sacc[c] = s_dblk[i - jb][c];
+      }
+#pragma unroll
+      for (int c = 0; c < XB; ++c) {
+        if (c < ncol && i >= jb + c) {
+          H[i + (long long)LD * (jb + c)] = sacc[c];
+          if (i > jb + c) H[jb + c + (long long)LD * i] = sacc[c];  // transposed copy: contiguous in c
+        }
+      }
+    }
+    if (ncol < XB) {  // info != 0: stop, go on with whatever is in H
+      if (tid == 0) {
+        H[(jb + ncol) + (long long)LD * (jb + ncol)] = s_piv;
+        s_info = jb + ncol + 1;
+      }
+      break;
+    }
+    __threadfence_block();
+    __syncthreads();
+  }
+  __syncthreads();
+  if (tid == 0) a.mt.potrf_info[slot] = s_info;
+}
+
+// B := B inv(L^T) inv(L) for 16 rows of the factor per wavefront, the slab (16 x rp doubles) LDS resident.
+// Per block of 16 columns, forward:  S = B_blk - Z[:, 0 : kb] L[kb : kb + 16, 0 : kb]^T  as kb / 4 chained
+// v_mfma_f64_16x16x4 (A = -Z from the slab, B = the factor's rows straight from the L2-resident block: 16
+// consecutive doubles per k), then the 16 x 16 triangle by substitution, one lane per row (the operations and
+// their order are dtrsm's Right/Lower/Trans; the sums of the block part run four k per matrix instruction).  Backward
+// (B inv(L)) the same from the right, reading the transposed copy of L.  Z stays fp64 in the slab between the
+// blocks (the one-workgroup body rounded it through the factor's storage type).  The rows' <z, z> = <x, g> go to
+// rowdot for the error; the jackknife row is zeroed by the scale launch.
+template <typename T>
+__global__ void __launch_bounds__(64) huge_solve_kernel(const UpdateArgs a_by_value) {
+  (void)a_by_value;
+  HUGE_PROLOGUE();
+  constexpr int LD = CALS_GLD;
+  const double *__restrict__ H = a.hscratch + (long long)h * CALS_GLD * CALS_GLD;
+  const int g = lane >> 4, n = lane & 15;
+  const int row0 = blockIdx.x * 16;
+  if (row0 >= I) return;
+  const int LDZ = rp + 4;  // rows four 8-byte banks apart: the 64 lanes of an A-operand read (row n, column k + g) hit every bank twice
+  double *slab = reinterpret_cast<double *>(upd_dyn);  // [16][LDZ]
+  double *dinv = slab + 16 * LDZ;                       // [rp]
+  double (*dblk)[17] = reinterpret_cast<double (*)[17]>(dinv + CALS_GLD);  // the diagonal block of the step
+  T *fac = static_cast<T *>(a.factor) + (long long)I * col;
+  const bool rok = row0 + n < I;
+  for (int c0 = 0; c0 < rp; c0 += 4) {
+    const int c = c0 + g;
+    slab[n * LDZ + c] = (rok && c < r) ? (double)fac[row0 + n + (long long)I * c] : 0.0;
+  }
+  for (int k = lane; k < rp; k += 64) dinv[k] = 1.0 / H[k + (long long)LD * k];
+  __syncthreads();
+  double rd = 0.0;
+  for (int kb = 0; kb < rp; kb += 16) {  // B := B inv(L^T)
+    double dl[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) dl[t] = H[(kb + n) + (long long)LD * (kb + g + 4 * t)];  // L[kb + n][kb + g + 4 t]
+    v4d acc;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) acc[v] = slab[(g + 4 * v) * LDZ + kb + n];
+    const double *hp = H + kb + n + (long long)LD * g;  // L[kb + n][k + g]
+    const double *zp = slab + n * LDZ + g;
+    int k = 0;
+    for (; k + 16 <= kb; k += 16) {
+      double bv[4], av[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        bv[u] = hp[(long long)LD * (k + 4 * u)];
+        av[u] = -zp[k + 4 * u];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int v = 0; v < 4; ++v) slab[(g + 4 * v) * LDZ + kb + n] = acc[v];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) dblk[n][g + 4 * t] = dl[t];
+    __syncthreads();
+    if (lane < 16) {
+      double s[16];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) s[c] = slab[lane * LDZ + kb + c];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        const double z = dinv[kb + c] * s[c];
+        s[c] = z;
+#pragma unroll
+        for (int c2 = c + 1; c2 < 16; ++c2) s[c2] -= dblk[c2][c] * z;
+      }
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        rd += s[c] * s[c];  // padding columns hold exact zeros
+        slab[lane * LDZ + kb + c] = s[c];
+      }
+    }
+    __syncthreads();
+  }
+  if (lane < 16 && row0 + lane < I) a.hrowdot[(long long)I * h + row0 + lane] = rd;
+  for (int jb = rp - 16; jb >= 0; jb -= 16) {  // B := B inv(L)
+    double dl[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) dl[t] = H[(jb + n) + (long long)LD * (jb + g + 4 * t)];
+    v4d acc;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) acc[v] = slab[(g + 4 * v) * LDZ + jb + n];
+    const double *hp = H + jb + n + (long long)LD * g;  // transposed copy: L[k + g][jb + n]
+    const double *zp = slab + n * LDZ + g;
+    for (int k = jb + 16; k < rp; k += 16) {
+      double bv[4], av[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        bv[u] = hp[(long long)LD * (k + 4 * u)];
+        av[u] = -zp[k + 4 * u];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int v = 0; v < 4; ++v) slab[(g + 4 * v) * LDZ + jb + n] = acc[v];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) dblk[n][g + 4 * t] = dl[t];
+    __syncthreads();
+    if (lane < 16) {
+      double s[16];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) s[c] = slab[lane * LDZ + jb + c];
+#pragma unroll
+      for (int j = 15; j >= 0; --j) {
+        double sj = s[j];
+#pragma unroll
+        for (int k = j + 1; k < 16; ++k) sj -= dblk[k][j] * s[k];  // L[jb + k][jb + j]
+        s[j] = dinv[jb + j] * sj;
+      }
+#pragma unroll
+      for (int c = 0; c < 16; ++c) slab[lane * LDZ + jb + c] = s[c];
+    }
+    __syncthreads();
+  }
+  for (int c0 = 0; c0 < rp; c0 += 4) {
+    const int c = c0 + g;
+    if (rok && c < r) fac[row0 + n + (long long)I * c] = (T)slab[n * LDZ + c];
+  }
+}
+
+// Column scales (Ktensor::normalize(mode, iteration)) and the normalisation, one wavefront per column; the jackknife
+// row is zeroed first (x * 0.0, as the other bodies: NaN / Inf stay visible).
+template <typename T>
+__global__ void __launch_bounds__(256) huge_scale_kernel(const UpdateArgs a_by_value) {
+  (void)a_by_value;
+  HUGE_PROLOGUE();
+  const int jkf = (a.mt.jk_mode[slot] == a.mode) ? a.mt.jk_fiber[slot] : -1;
+  const bool first = (a.mt.iters[slot] == 1);
+  T *fac = static_cast<T *>(a.factor) + (long long)I * col;
+  for (int c = blockIdx.x * 4 + wave; c < r; c += gridDim.x * 4) {
+    T *cp = fac + (long long)I * c;
+    if (jkf >= 0 && jkf < I && lane == (jkf & 63)) cp[jkf] = (T)((double)cp[jkf] * 0.0);  // (this lane re-reads it below)
+    double lam;
+    if (first) {
+      double ss = 0.0;
+      for (int i = lane; i < I; i += 64) {
+        const double x = (double)cp[i];
+        ss += x * x;
+      }
+      lam = sqrt(wave_sum(ss));
+    } else {
+      double m = -1.0, v = 0.0;
+      int ix = 0x7fffffff;
+      for (int i = lane; i < I; i += 64) {
+        const double x = (double)cp[i];
+        const double ax = fabs(x);
+        if (ax > m) {
+          m = ax;
+          v = x;
+          ix = i;
+        }
+      }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        const double m2 = __shfl_xor(m, off);
+        const double v2 = __shfl_xor(v, off);
+        const int i2 = __shfl_xor(ix, off);
+        const bool take = (m2 > m) || (m2 == m && i2 < ix);
+        m = take ? m2 : m;
+        v = take ? v2 : v;
+        ix = take ? i2 : ix;
+      }
+      lam = v;
+    }
+    if (lane == 0) a.lambda[col + c] = lam;
+    if (lam != 0.0)
+      for (int i = lane; i < I; i += 64) cp[i] = (T)((1.0 / lam) * (double)cp[i]);
+  }
+}
+
+// update_gramian: one 16 x 16 tile pair (bi <= bj) per workgroup, rows split over the waves and summed in wave
+// order -- the one-workgroup body's sums, tile by tile.
+template <typename T>
+__global__ void __launch_bounds__(256) huge_gram_kernel(const UpdateArgs a_by_value) {
+  (void)a_by_value;
+  HUGE_PROLOGUE();
+  const int nt = (r + 15) >> 4;
+  int bi = 0, p = blockIdx.x;
+  while (bi < nt && p >= nt - bi) {
+    p -= nt - bi;
+    ++bi;
+  }
+  if (bi >= nt) return;
+  const int bj = bi + p;
+  const T *fac = static_cast<const T *>(a.factor) + (long long)I * col;
+  __shared__ double gpb[UPD_WAVES * 256];
+  const int chunk = ((I + UPD_WAVES - 1) / UPD_WAVES + 3) / 4 * 4;
+  const int row0 = wave * chunk, row1 = min(I, row0 + chunk);
+  const int krow = lane >> 4, lcol = lane & 15;
+  const v4d t = gramian_tile_b8(fac, row0, row1, (long long)I, r, lane, bi, bj);
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg) gpb[wave * 256 + lane * 4 + reg] = t[reg];
+  __syncthreads();
+  if (wave == 0) {
+    double *gm = a.gram[a.mode] + CALS_GLD * (long long)col;
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int e = lane * 4 + reg;
+      const double v = ((gpb[e] + gpb[256 + e]) + gpb[512 + e]) + gpb[768 + e];
+      const int row = 16 * bi + krow + 4 * reg, cc = 16 * bj + lcol;
+      if (row < r && cc < r) {
+        gm[row + CALS_GLD * cc] = v;
+        gm[cc + CALS_GLD * row] = v;
+      }
+    }
+  }
+}
+
+// Fast error of the last mode (error::compute_fast_error) + the end-of-sweep rule.
+__global__ void __launch_bounds__(256) huge_error_kernel(const UpdateArgs a_by_value) {
+  (void)a_by_value;
+  HUGE_PROLOGUE();
+  const int jkf = (a.mt.jk_mode[slot] == a.mode) ? a.mt.jk_fiber[slot] : -1;
+  const double *rowdot = a.rowdot ? a.rowdot + (long long)I * k_model : a.hrowdot + (long long)I * h;
+  __shared__ double redt[UPD_WAVES];
+  double t3 = 0.0;
+  for (int i0 = tid; i0 < I; i0 += 2 * UPD_THREADS)
+#pragma unroll
+    for (int nn = 0; nn < 2; ++nn) {
+      const int i = i0 + nn * UPD_THREADS;
+      if (i < I && i != jkf) t3 += rowdot[i];
+    }
+  t3 = wave_sum(t3);
+  if (lane == 0) redt[wave] = t3;
+  __syncthreads();
+  t3 = redt[0] + redt[1] + redt[2] + redt[3];
+  __syncthreads();
+  double t2 = 0.0;
+  for (int e = tid; e < r * r; e += UPD_THREADS) {
+    const int i = e % r, j = e / r;
+    double hh = 1.0;
+    for (int m = 0; m < a.n_modes; ++m) hh *= a.gram[m][i + CALS_GLD * (long long)(col + j)];
+    t2 += a.lambda[col + i] * a.lambda[col + j] * hh;
+  }
+  t2 = wave_sum(t2);
+  if (lane == 0) redt[wave] = t2;
+  __syncthreads();
+  if (tid == 0) {
+    t2 = redt[0] + redt[1] + redt[2] + redt[3];
+    const int jm = a.mt.jk_mode[slot];
+    const double xn = (jm >= 0) ? a.jk_norms[a.mt.jk_fiber[slot]] : a.X_norm;
+    const double e2 = fmax(xn * xn + t2 - 2.0 * t3, 0.0);
+    const double err = sqrt(e2);
+    a.mt.err[slot] = err;
+    const double of = a.mt.fit[slot];
+    a.mt.old_fit[slot] = of;
+    a.mt.fit[slot] = 1.0 - fabs(err) / a.X_norm;
+    if (a.fin.on) apply_finish_rule(a, slot);
+  }
+}
+#undef HUGE_PROLOGUE
 
 // G[i, c] = sum_t partial[(c / 128) * T + t][i, c % 128], t = 0..T-1 in this fixed order
 // (deterministic split-K reduction of the MTTKRP, summed in fp64), written into the multi-factor
@@ -1582,6 +2004,7 @@ hipError_t update_launch(const UpdateArgs &a_in, int rmax_needed, hipStream_t st
   static const bool no_lds = getenv("CALS_UPDATE_NO_LDS") != nullptr;  // A/B switch
   const bool f32 = a.dtype == CALS_F32;
   const bool small = (classes & 1) != 0 || classes == 0, big = (classes & 2) != 0 || classes == 0;
+  const bool huge = (classes & 4) != 0 || (classes == 0 && rmax_needed > CALS_RMAX);
   hipError_t e = hipSuccess;
   if (small) {
     if (dyn <= budget && !no_lds) {
@@ -1602,7 +2025,7 @@ hipError_t update_launch(const UpdateArgs &a_in, int rmax_needed, hipStream_t st
         hipLaunchKernelGGL(update_hbm_kernel<double>, dim3(a.n_slots), dim3(UPD_THREADS), 0, st, a);
     }
   }
-  if (big && (rmax_needed > CALS_RFAST || classes == 0)) {
+  if (big && (rmax_needed > CALS_RFAST || classes == 0)) {  // ranks 33..64
     // ranks 33..64: update_body_huge<T, true> keeps H (64 columns, ld 66) + 4 partial tiles in dynamic LDS
     const size_t hdyn = (size_t)(UPD_HLDS_LD * CALS_RMAX + UPD_WAVES * 256) * sizeof(double);
     a.xld = 0;
@@ -1614,6 +2037,30 @@ hipError_t update_launch(const UpdateArgs &a_in, int rmax_needed, hipStream_t st
       if ((e = upd_raise_lds(&update_huge_kernel<double>, once_f64, budget)) != hipSuccess) return e;
       hipLaunchKernelGGL(update_huge_kernel<double>, dim3(a.n_slots), dim3(UPD_THREADS), hdyn, st, a);
     }
+  }
+  if (huge) {  // ranks 65..CALS_GLD: the pipeline of huge_* launches over the class's models
+    if (!a.huge_idx || a.n_huge <= 0 || !a.hscratch || (!a.rowdot && !a.hrowdot)) return hipErrorInvalidValue;
+    const int rp = std::min((rmax_needed + 15) & ~15, CALS_GLD), nt = rp / 16;
+    const unsigned nh = (unsigned)a.n_huge;
+    a.xld = 0;
+    if (!a.rowdot) {
+      hipLaunchKernelGGL(huge_hadamard_kernel, dim3(rp / 4, nh), dim3(256), 0, st, a);
+      hipLaunchKernelGGL(huge_potrf_kernel, dim3(1, nh), dim3(256), 0, st, a);
+      const size_t sdyn = (size_t)(16 * (rp + 4) + CALS_GLD + 16 * 17) * sizeof(double);
+      const dim3 sgrid((a.I + 15) / 16, nh);
+      if (f32)
+        hipLaunchKernelGGL(huge_solve_kernel<float>, sgrid, dim3(64), sdyn, st, a);
+      else
+        hipLaunchKernelGGL(huge_solve_kernel<double>, sgrid, dim3(64), sdyn, st, a);
+    }
+    if (f32) {
+      hipLaunchKernelGGL(huge_scale_kernel<float>, dim3(rp / 4, nh), dim3(256), 0, st, a);
+      hipLaunchKernelGGL(huge_gram_kernel<float>, dim3(nt * (nt + 1) / 2, nh), dim3(256), 0, st, a);
+    } else {
+      hipLaunchKernelGGL(huge_scale_kernel<double>, dim3(rp / 4, nh), dim3(256), 0, st, a);
+      hipLaunchKernelGGL(huge_gram_kernel<double>, dim3(nt * (nt + 1) / 2, nh), dim3(256), 0, st, a);
+    }
+    if (a.is_last) hipLaunchKernelGGL(huge_error_kernel, dim3(1, nh), dim3(256), 0, st, a);
   }
   return hipGetLastError();
 }
