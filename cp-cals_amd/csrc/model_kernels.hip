@@ -908,30 +908,29 @@ __device__ __forceinline__ v4d gramian_tile_b8(PTR panel, int row0, int row1, lo
   return acc;
 }
 
-// Ranks 65..CALS_GLD: no register file or LDS holds an r x r matrix or a factor row of this size, so H / L
-// live in a global scratch block per workgroup (a.hscratch, L2 resident) and the rows are solved through the
-// factor panel itself, one row per thread, SIXTEEN COLUMNS AT A TIME in registers:
-//   * dpotf2 on the whole workgroup (thread = row; column j needs sum_{k<j} L[i][k] L[j][k]: own row
-//     coalesced over the threads, row j broadcast); every L[i][j] is also written TRANSPOSED into the upper
-//     triangle of the block, so that both substitutions below read 16 consecutive doubles per step; the
-//     loads of eight k go out before their FMAs (an exposed L2 round trip per FMA was 85 % of this body);
+// Ranks 33..CALS_RMAX (64): too wide for the register-resident bodies above; H / L (64 columns, ld 66: the
+// transposed-copy stores of a wave spread over 16 banks instead of one) live in dynamic LDS and the rows are solved
+// through the factor panel itself, one row per thread, SIXTEEN COLUMNS AT A TIME in registers:
+//   * dpotf2 on the whole workgroup (thread = row; column j needs sum_{k<j} L[i][k] L[j][k]: own row over the
+//     threads, row j broadcast); every L[i][j] is also written TRANSPOSED into the upper triangle of the block, so
+//     that both substitutions below read 16 consecutive doubles (ds_read_b128) per step; the Cholesky panels run
+//     on one wave;
 //   * B := B inv(L^T), left-looking per 16-column block: x_b -= L[b, k] x_k over all earlier columns k in
 //     ascending order, then the 16 x 16 triangle -- the operations and their order are dtrsm's
 //     Right/Lower/Trans; B := B inv(L) block by block from the right, later columns first, then the triangle
 //     (the sums of a column run over the same terms as dtrsm's in a different order: rounding only);
 //   * H is padded with the identity up to a multiple of 16 columns, so no step carries a `c < r` guard.
 // Same tail as the other bodies (statistics, scaling, Gramian on the matrix cores, error).  After the NNLS
-// update (a.rowdot, nnls_huge_kernel) the panel already holds the solution and only the tail runs.
-// HLDS (ranks 33..64): the same code with the H / L block in dynamic LDS (ld 66: the transposed-copy stores of a
-// wave then spread over 16 banks instead of one) -- the Cholesky panels run on one wave, the substitutions read L
-// with ds_read_b128.  (Round 1's body for these ranks unrolled a 64 x 64 guarded substitution per row: 4096 LDS
-// reads and exec-mask guards per thread, 0.7 ms per launch at rank 64 -- slower than this code through L2.)
+// update (a.rowdot) the panel already holds the solution and only the tail runs.
+// (Round 1's body for these ranks unrolled a 64 x 64 guarded substitution per row: 4096 LDS reads and exec-mask
+// guards per thread, 0.7 ms per launch at rank 64.  Until round 3 this body, with H / L in a global scratch block,
+// also served ranks 65..CALS_GLD on one workgroup: 2.6 ms per mode at rank 256 -- now the huge_* launches below.)
 #define UPD_HLDS_LD 66
-template <typename T, bool HLDS>
+template <typename T>
 static __device__ UPD_BODY_ATTR void update_body_huge(UpdArgsPtr a_ptr, int slot, int r,
                                                            UpdShared &sh) {
   UpdArgsRef a = upd_uniform(a_ptr);  // the calling kernel's argument block (constant memory, scalar loads)
-  constexpr int LD = HLDS ? UPD_HLDS_LD : CALS_GLD;
+  constexpr int LD = UPD_HLDS_LD;
   constexpr int XB = 16;
   typedef double v2d __attribute__((ext_vector_type(2)));
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -941,23 +940,15 @@ static __device__ UPD_BODY_ATTR void update_body_huge(UpdArgsPtr a_ptr, int slot
   const int I = a.I;
   const int rp = (r + XB - 1) / XB * XB;
   // [UPD_WAVES][256] partial Gramian tiles
-  double *gpb = reinterpret_cast<double *>(upd_dyn) + (HLDS ? UPD_HLDS_LD * CALS_RMAX : 0);
+  double *gpb = reinterpret_cast<double *>(upd_dyn) + UPD_HLDS_LD * CALS_RMAX;
   __shared__ double s_piv;
   // the diagonal block of a Cholesky panel: in the Gramian-partials area of UpdShared, idle at that point
   double (*s_dblk)[XB + 1] = reinterpret_cast<double (*)[XB + 1]>(&sh.gp[0][0][0]);
-  __shared__ int s_info, s_block, s_fail;
-  // scratch blocks are handed out in arrival order (the engine sizes the pool by the number of such models
-  // in flight and zeroes the counter before the launch)
+  __shared__ int s_info, s_fail;
   const double *rowdot = a.rowdot ? a.rowdot + (long long)I * blockIdx.x : nullptr;
   const bool solved = rowdot != nullptr;
   UPD_STAMP_H(0);
-  if (tid == 0) s_block = (solved || HLDS) ? 0 : atomicAdd(a.hcounter, 1);
-  __syncthreads();
-  double *__restrict__ H;  // rp x rp, ld LD
-  if constexpr (HLDS)
-    H = reinterpret_cast<double *>(upd_dyn);
-  else
-    H = a.hscratch + (long long)s_block * LD * LD;
+  double *__restrict__ H = reinterpret_cast<double *>(upd_dyn);  // rp x rp, ld LD
 
   for (int e = tid; e < (solved ? 0 : rp * rp); e += UPD_THREADS) {
     const int i = e % rp, j = e / rp;
@@ -1419,7 +1410,7 @@ __global__ void __launch_bounds__(UPD_THREADS, 1) update_huge_kernel(const Updat
   const int slot = a.slots[blockIdx.x];
   const int r = a.mt.rank[slot];
   if (r <= CALS_RFAST || r > CALS_RMAX) return;  // above CALS_RMAX: the huge_* launches (update_launch)
-  update_body_huge<T, true>(a_ptr, slot, r, sh);
+  update_body_huge<T>(a_ptr, slot, r, sh);
 }
 #undef UPD_DISPATCH
 
@@ -1437,6 +1428,26 @@ __global__ void __launch_bounds__(UPD_THREADS, 1) update_huge_kernel(const Updat
 // Model h of the class (UpdateArgs::huge_idx) owns block h of hscratch -- no counter.  After the NNLS update
 // (a.rowdot) the factor and the solve launches are skipped, as the `solved` path of the other bodies.
 // ---------------------------------------------------------------------------------------------
+#ifdef CALS_DIAG  // phase cycle sums of workgroup (0, 0) at mode 0 into the trace (tools/update_trace_huge.py)
+#define HUGE_CLK_DECL(N)                     \
+  unsigned long long hclk[N] = {};           \
+  unsigned long long hclk_t = __builtin_amdgcn_s_memtime()
+#define HUGE_CLK(k)                                                \
+  do {                                                             \
+    const unsigned long long now_ = __builtin_amdgcn_s_memtime();  \
+    hclk[k] += now_ - hclk_t;                                      \
+    hclk_t = now_;                                                 \
+  } while (0)
+#define HUGE_CLK_DUMP(N, at)                                                                       \
+  do {                                                                                             \
+    if (a.dbg_trace && a.mode == 0 && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)      \
+      for (int q_ = 0; q_ < N; ++q_) a.dbg_trace[(at) + q_] = hclk[q_];                            \
+  } while (0)
+#else
+#define HUGE_CLK_DECL(N) do { } while (0)
+#define HUGE_CLK(k) do { } while (0)
+#define HUGE_CLK_DUMP(N, at) do { } while (0)
+#endif
 #define HUGE_PROLOGUE()                                                      \
   UpdArgsRef a = *upd_kernargs();                                            \
   const int h = blockIdx.y;                                                  \
@@ -1464,68 +1475,67 @@ __global__ void __launch_bounds__(256) huge_hadamard_kernel(const UpdateArgs a_b
     }
 }
 
-// dpotf2 in panels of 16 columns, thread = row (rp <= 256 rows, the padding rows are identity rows):
-//   S[i][c] = H[i][jb + c] - sum_{k < jb} L[i][k] L[jb + c][k]   in registers, four k in flight;
-//   the 16 x 16 diagonal block goes to LDS, where wave 0 factors it column by column (right-looking inside
-//   the block); every row below it then applies the block's columns to its own 16 values.
-// Every entry sees the subtractions of dpotf2 in dpotf2's order (k ascending), so the factor is the unblocked
-// one bit for bit; a non-positive pivot stops at its column with the earlier columns final and the rest of H
-// untouched, exactly the state the column-by-column form leaves (update.cpp:183-185 only logs info).  Every
-// L[i][j] is also written TRANSPOSED into the upper triangle of the block, so that both substitutions of the
-// solve read 16 consecutive doubles per step.
-__global__ void __launch_bounds__(256) huge_potrf_kernel(const UpdateArgs a_by_value) {
+// dpotrf, lower, in panels of 16 columns (rp <= 256 rows, the padding rows are identity rows), left-looking:
+//   (a) S = H[jb :, jb : jb + 16] - L[jb :, 0 : jb] L[jb : jb + 16, 0 : jb]^T  one 16 x 16 tile per wavefront at a time
+//       as jb / 4 chained v_mfma_f64_16x16x4 (both operands straight from the L2-resident block: column-major L,
+//       16 consecutive doubles per k), the tiles into LDS;
+//   (b) wave 0 factors the diagonal tile column by column (right-looking inside the tile: lane = row, the row in
+//       registers, pivot and finished column by v_readlane);
+//   (c) thread = row below the tile applies the tile's columns to its 16 values (dtrsm) and writes the finished
+//       columns -- also TRANSPOSED into the upper triangle, so that (a) and both substitutions of the solve read 16
+//       consecutive doubles per step.
+// The sums of an entry run over dpotf2's terms, k ascending, four per matrix instruction (the one-workgroup body took
+// them one by one: 0.42 ms at rank 256 against 0.07 here).  A non-positive pivot stops at its column with the earlier
+// columns final and the rest of H untouched -- the state the column-by-column form leaves (update.cpp:183-185 only
+// logs info).
+#define HUGE_POTRF_THREADS 512
+__global__ void __launch_bounds__(HUGE_POTRF_THREADS) huge_potrf_kernel(const UpdateArgs a_by_value) {
   (void)a_by_value;
   HUGE_PROLOGUE();
-  constexpr int XB = 16, LD = CALS_GLD;
-  typedef double v2d __attribute__((ext_vector_type(2)));
+  constexpr int XB = 16, LD = CALS_GLD, W = HUGE_POTRF_THREADS / 64;
   double *__restrict__ H = a.hscratch + (long long)h * CALS_GLD * CALS_GLD;
-  __shared__ double s_dblk[XB][XB + 1];
-  __shared__ double s_piv;
+  __shared__ double s_tile[CALS_GLD / XB][XB][XB + 1];  // the panel's S tiles; tile 0 = the diagonal block
+  __shared__ double s_piv, s_rdiag[XB];
   __shared__ int s_info, s_fail;
+  const int g = lane >> 4, n = lane & 15;
   if (tid == 0) s_info = 0;
   __syncthreads();
+  HUGE_CLK_DECL(3);
   for (int jb = 0; jb < rp; jb += XB) {
-    const int i = tid;
-    const bool act = i >= jb && i < rp;
-    double sacc[XB];
+    const int ntile = (rp - jb) / XB;
+    for (int t = wave; t < ntile; t += W) {  // (a)
+      const int row0 = jb + XB * t;
+      v4d acc;
+      // H is symmetric and columns >= jb of rows >= jb are still H's: the transposed entry, contiguous over the lanes
 #pragma unroll
-    for (int c = 0; c < XB; ++c) sacc[c] = 0.0;
-    if (act) {
+      for (int v = 0; v < 4; ++v) acc[v] = H[(jb + n) + (long long)LD * (row0 + g + 4 * v)];
+      const double *ap = H + row0 + n + (long long)LD * g;  // L[row0 + n][k + g]
+      const double *bp = H + jb + n + (long long)LD * g;    // L[jb + n][k + g]
+      // segments of 28 instructions (112 columns): ALL operand loads of a segment go out before its first
+      // instruction -- one L2 round trip per segment (a chunk-by-chunk pipeline exposed part of every chunk's: 130 us
+      // of this kernel's 240 at rank 256)
+      for (int ks = 0; ks < jb; ks += 112) {
+        double av[28], bv[28];
 #pragma unroll
-      for (int c = 0; c < XB; ++c) sacc[c] = H[i + (long long)LD * (jb + c)];
-      for (int k = 0; k < jb; k += 4) {
-        double own[4];
-        v2d pan[4][XB / 2];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          own[u] = H[i + (long long)LD * (k + u)];
-          const v2d *hp = reinterpret_cast<const v2d *>(H + jb + (long long)LD * (k + u));  // L[jb + c][k + u]
-#pragma unroll
-          for (int c = 0; c < XB / 2; ++c) pan[u][c] = hp[c];
+        for (int u = 0; u < 28; ++u) {
+          const bool in = ks + 4 * (u & ~3) < jb;  // jb is a multiple of 16: whole groups of four
+          av[u] = in ? -ap[(long long)LD * (ks + 4 * u)] : 0.0;
+          bv[u] = in ? bp[(long long)LD * (ks + 4 * u)] : 0.0;
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-#pragma unroll
-          for (int c = 0; c < XB; c += 2) {
-            sacc[c] -= own[u] * pan[u][c >> 1][0];
-            sacc[c + 1] -= own[u] * pan[u][c >> 1][1];
-          }
-        }
+        for (int u = 0; u < 28; ++u)
+          if (ks + 4 * (u & ~3) < jb) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
       }
-      if (i < jb + XB) {
 #pragma unroll
-        for (int c = 0; c < XB; ++c) s_dblk[i - jb][c] = sacc[c];
-      }
+      for (int v = 0; v < 4; ++v) s_tile[t][g + 4 * v][n] = acc[v];
     }
     if (tid == 0) s_fail = XB;
     __syncthreads();
-    if (wave == 0) {
-      // lane = row of the block, the row in registers; column c: the pivot and the finished column travel by
-      // v_readlane.  Right-looking inside the block: entry (row, c2) sees the subtractions k = jb, jb + 1, ...
-      // in dpotf2's order.  Lanes >= 16 compute on zeros.
+    HUGE_CLK(0);
+    if (wave == 0) {  // (b) lanes >= 16 compute on zeros
       double rv[XB];
 #pragma unroll
-      for (int c = 0; c < XB; ++c) rv[c] = (lane < XB) ? s_dblk[lane][c] : 0.0;
+      for (int c = 0; c < XB; ++c) rv[c] = (lane < XB) ? s_tile[0][lane][c] : 0.0;
       int fail = XB;
       double fpiv = 0.0;
 #pragma unroll
@@ -1536,9 +1546,14 @@ __global__ void __launch_bounds__(256) huge_potrf_kernel(const UpdateArgs a_by_v
             fail = c;
             fpiv = piv;
           } else {
-            const double lcc = sqrt(piv);
-            const double l = (lane == c) ? lcc : rv[c] / lcc;
+            // 1 / sqrt(pivot): v_rsq_f64 + two Newton steps, the column scaled by it (dpotf2 scales by ONE / AJJ too;
+            // an IEEE sqrt and sixteen IEEE divides per column were 8.5 k cycles per tile, all of it serial)
+            double rl = __builtin_amdgcn_rsq(piv);
+            rl = rl * fma(-0.5 * piv * rl, rl, 1.5);
+            rl = rl * fma(-0.5 * piv * rl, rl, 1.5);
+            const double l = (lane == c) ? piv * rl : rv[c] * rl;
             rv[c] = l;
+            if (lane == 0) s_rdiag[c] = rl;
 #pragma unroll
             for (int c2 = c + 1; c2 < XB; ++c2) {
               const double lc2 = lane_bcast(l, c2);  // L[c2][c]
@@ -1549,7 +1564,7 @@ __global__ void __launch_bounds__(256) huge_potrf_kernel(const UpdateArgs a_by_v
       }
       if (lane < XB) {
 #pragma unroll
-        for (int c = 0; c < XB; ++c) s_dblk[lane][c] = rv[c];
+        for (int c = 0; c < XB; ++c) s_tile[0][lane][c] = rv[c];
       }
       if (lane == 0 && fail < XB) {
         s_fail = fail;
@@ -1557,21 +1572,23 @@ __global__ void __launch_bounds__(256) huge_potrf_kernel(const UpdateArgs a_by_v
       }
     }
     __syncthreads();
+    HUGE_CLK(1);
     const int ncol = s_fail;  // columns of this panel that are final
-    if (act) {
-      if (i >= jb + XB) {  // below the block: L[i][jb + c] = (S[i][c] - sum_{c' < c} L[i][jb + c'] L[jb + c][jb + c']) / L_cc
+    const int i = jb + tid;   // (c)
+    if (i < rp) {
+      double sacc[XB];
+#pragma unroll
+      for (int c = 0; c < XB; ++c) sacc[c] = s_tile[tid >> 4][tid & 15][c];
+      if (tid >= XB) {  // below the tile: L[i][jb + c] = (S[i][c] - sum_{c' < c} L[i][jb + c'] L[jb + c][jb + c']) / L_cc
 #pragma unroll
         for (int c = 0; c < XB; ++c) {
           if (c < ncol) {
-            const double l = sacc[c] / s_dblk[c][c];
+            const double l = sacc[c] * s_rdiag[c];  // (dtrsm scales by ONE / A(K,K) as well)
             sacc[c] = l;
 #pragma unroll
-            for (int c2 = c + 1; c2 < XB; ++c2) sacc[c2] -= l * s_dblk[c2][c];
+            for (int c2 = c + 1; c2 < XB; ++c2) sacc[c2] -= l * s_tile[0][c2][c];
           }
         }
-      } else {
-#pragma unroll
-        for (int c = 0; c < XB; ++c) sacc[c] = s_dblk[i - jb][c];
       }
 #pragma unroll
       for (int c = 0; c < XB; ++c) {
@@ -1590,24 +1607,42 @@ __global__ void __launch_bounds__(256) huge_potrf_kernel(const UpdateArgs a_by_v
     }
     __threadfence_block();
     __syncthreads();
+    HUGE_CLK(2);
   }
   __syncthreads();
   if (tid == 0) a.mt.potrf_info[slot] = s_info;
+  HUGE_CLK_DUMP(3, 0);  // CALS_DIAG: cycles in (a) tiles, (b) diagonal tile, (c) rows below + stores
 }
 
 // B := B inv(L^T) inv(L) for 16 rows of the factor per wavefront, the slab (16 x rp doubles) LDS resident.
 // Per block of 16 columns, forward:  S = B_blk - Z[:, 0 : kb] L[kb : kb + 16, 0 : kb]^T  as kb / 4 chained
-// v_mfma_f64_16x16x4 (A = -Z from the slab, B = the factor's rows straight from the L2-resident block: 16
-// consecutive doubles per k), then the 16 x 16 triangle by substitution, one lane per row (the operations and
-// their order are dtrsm's Right/Lower/Trans; the sums of the block part run four k per matrix instruction).  Backward
-// (B inv(L)) the same from the right, reading the transposed copy of L.  Z stays fp64 in the slab between the
-// blocks (the one-workgroup body rounded it through the factor's storage type).  The rows' <z, z> = <x, g> go to
-// rowdot for the error; the jackknife row is zeroed by the scale launch.
+// v_mfma_f64_16x16x4 (A = -Z from the slab, B = the block's 16 rows of L), then the 16 x 16 triangle by substitution,
+// one lane per row (the operations and their order are dtrsm's Right/Lower/Trans; the sums of the block part run four
+// k per matrix instruction).  Backward (B inv(L)) the same from the right, with the transposed copy of L.
+// The rows of L a block needs -- [k][16] doubles, k over the block's columns incl. its own triangle -- arrive by
+// LDS-DMA (global_load_lds_dwordx4: eight k per instruction, each 16 consecutive doubles of the L2-resident factor),
+// issued ONE BLOCK AHEAD into the other half of a double buffer: they do not depend on the slab, and a lone wave on
+// its CU has nothing else to cover an L2 round trip (with register loads in front of their instructions this kernel
+// took 173 us at rank 256, three quarters of it waiting; the compiler's counters cannot look across the blocks).
+// Z stays fp64 in the slab between the blocks (the one-workgroup body rounded it through the factor's storage type).
+// The rows' <z, z> = <x, g> go to hrowdot for the error; the jackknife row is zeroed by the scale launch.
+#ifndef GLOBAL_AS
+#define GLOBAL_AS __attribute__((address_space(1)))
+#define LDS_AS __attribute__((address_space(3)))
+#endif
+// (one wavefront per workgroup: LDS traffic of a wave is ordered, a wavefront-scope fence is all the steps need)
+#define HUGE_WAVE_SYNC()                                      \
+  do {                                                        \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");    \
+    __builtin_amdgcn_wave_barrier();                          \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");    \
+  } while (0)
+#define HUGE_SOLVE_LDS_DOUBLES(rp) (16 * ((rp) + 4) + CALS_GLD + 2 * 16 * CALS_GLD)
 template <typename T>
 __global__ void __launch_bounds__(64) huge_solve_kernel(const UpdateArgs a_by_value) {
   (void)a_by_value;
   HUGE_PROLOGUE();
-  constexpr int LD = CALS_GLD;
+  constexpr int LD = CALS_GLD, PANEL = 16 * CALS_GLD;
   const double *__restrict__ H = a.hscratch + (long long)h * CALS_GLD * CALS_GLD;
   const int g = lane >> 4, n = lane & 15;
   const int row0 = blockIdx.x * 16;
@@ -1615,51 +1650,97 @@ __global__ void __launch_bounds__(64) huge_solve_kernel(const UpdateArgs a_by_va
   const int LDZ = rp + 4;  // rows four 8-byte banks apart: the 64 lanes of an A-operand read (row n, column k + g) hit every bank twice
   double *slab = reinterpret_cast<double *>(upd_dyn);  // [16][LDZ]
   double *dinv = slab + 16 * LDZ;                       // [rp]
-  double (*dblk)[17] = reinterpret_cast<double (*)[17]>(dinv + CALS_GLD);  // the diagonal block of the step
+  double *Lp = dinv + CALS_GLD;                         // [2][PANEL]: the block's rows of L, [k][16]
   T *fac = static_cast<T *>(a.factor) + (long long)I * col;
   const bool rok = row0 + n < I;
-  for (int c0 = 0; c0 < rp; c0 += 4) {
-    const int c = c0 + g;
-    slab[n * LDZ + c] = (rok && c < r) ? (double)fac[row0 + n + (long long)I * c] : 0.0;
-  }
-  for (int k = lane; k < rp; k += 64) dinv[k] = 1.0 / H[k + (long long)LD * k];
-  __syncthreads();
-  double rd = 0.0;
-  for (int kb = 0; kb < rp; kb += 16) {  // B := B inv(L^T)
-    double dl[4];
+  // rows k0 .. k1 - 1 of H[(blk + 0..15) + LD k] -> Lp[buf][(k - k0)][16]; lane: 16 bytes = doubles 2 (lane & 7), +1 of k0 + lane / 8
+  const double *hsrc = H + 2 * (lane & 7) + (long long)LD * (lane >> 3);
+  auto issue_panel = [&](int blk, int k0, int k1, int buf) {
+    for (int k = k0; k < k1; k += 8)
+      __builtin_amdgcn_global_load_lds((const GLOBAL_AS void *)(hsrc + blk + (long long)LD * k),
+                                       (LDS_AS void *)(Lp + buf * PANEL + (k - k0) * 16), 16, 0, 0);
+  };
+  issue_panel(0, 0, 16, 0);
+  for (int c0 = 0; c0 < rp; c0 += 64) {  // (rp is a multiple of 16: batches of 16 loads in flight, not one round trip each)
+    double tmp[16];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) dl[t] = H[(kb + n) + (long long)LD * (kb + g + 4 * t)];  // L[kb + n][kb + g + 4 t]
+    for (int u = 0; u < 16; ++u) {
+      const int c = c0 + 4 * u + g;
+      tmp[u] = (rok && c < r) ? (double)fac[row0 + n + (long long)I * c] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u)
+      if (c0 + 4 * u < rp) slab[n * LDZ + c0 + 4 * u + g] = tmp[u];
+  }
+  {
+    double dv[CALS_GLD / 64];
+#pragma unroll
+    for (int u = 0; u < CALS_GLD / 64; ++u) dv[u] = (lane + 64 * u < rp) ? H[(lane + 64 * u) * (long long)(LD + 1)] : 1.0;
+#pragma unroll
+    for (int u = 0; u < CALS_GLD / 64; ++u)
+      if (lane + 64 * u < rp) dinv[lane + 64 * u] = 1.0 / dv[u];
+  }
+  double rd = 0.0;
+  int buf = 0;
+  HUGE_CLK_DECL(5);
+  const double *zp = slab + n * LDZ + g;  // A operand: Z[row n][k + g]
+  // the block part: acc -= Z[:, k0 : k1] Lblk^T, Lblk's rows at lp[(k - k0) * 16]; the operands of the next four
+  // instructions are read while the current four run
+  auto gemm = [&](v4d acc, const double *lp, int k0, int k1) {
+    double av[2][4], bv[2][4];
+    auto rd4 = [&](int k, int q) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        av[q][u] = -zp[k + 4 * u];
+        bv[q][u] = lp[(k - k0 + 4 * u) * 16];
+      }
+    };
+    if (k0 < k1) rd4(k0, 0);
+    for (int k = k0; k < k1; k += 32) {
+      if (k + 16 < k1) rd4(k + 16, 1);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[0][u], bv[0][u], acc, 0, 0, 0);
+      if (k + 32 < k1) rd4(k + 32, 0);
+      if (k + 16 < k1) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[1][u], bv[1][u], acc, 0, 0, 0);
+      }
+    }
+    return acc;  // (two alternating accumulators measured no faster: the chain of dependent instructions is not the limit)
+  };
+  for (int kb = 0; kb < rp; kb += 16, buf ^= 1) {  // B := B inv(L^T); panel = rows 0 .. kb + 15 of L[kb + n][k]
+    HUGE_CLK(4);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    HUGE_WAVE_SYNC();
+    HUGE_CLK(0);
+    if (kb + 16 < rp) issue_panel(kb + 16, 0, kb + 32, buf ^ 1);
+    HUGE_CLK(1);
+    const double *lp = Lp + buf * PANEL;
     v4d acc;
 #pragma unroll
     for (int v = 0; v < 4; ++v) acc[v] = slab[(g + 4 * v) * LDZ + kb + n];
-    const double *hp = H + kb + n + (long long)LD * g;  // L[kb + n][k + g]
-    const double *zp = slab + n * LDZ + g;
-    int k = 0;
-    for (; k + 16 <= kb; k += 16) {
-      double bv[4], av[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        bv[u] = hp[(long long)LD * (k + 4 * u)];
-        av[u] = -zp[k + 4 * u];
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
-    }
+    acc = gemm(acc, lp + g * 16 + n, 0, kb);
 #pragma unroll
     for (int v = 0; v < 4; ++v) slab[(g + 4 * v) * LDZ + kb + n] = acc[v];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) dblk[n][g + 4 * t] = dl[t];
-    __syncthreads();
+    HUGE_WAVE_SYNC();
+    HUGE_CLK(2);
     if (lane < 16) {
-      double s[16];
-#pragma unroll
-      for (int c = 0; c < 16; ++c) s[c] = slab[lane * LDZ + kb + c];
+      // lane = row of the slab AND row of the triangle: L[kb + lane][kb + c] in dr[c]; the entry a step needs is the
+      // same for every row -- it travels by v_readlane into an SGPR pair (as 136 broadcast LDS reads, each in front of
+      // its FMA, the triangle was three quarters of this kernel)
+      double s[16], dr[16];
 #pragma unroll
       for (int c = 0; c < 16; ++c) {
-        const double z = dinv[kb + c] * s[c];
+        s[c] = slab[lane * LDZ + kb + c];
+        dr[c] = lp[(kb + c) * 16 + lane];
+      }
+      const double dvl = dinv[kb + lane];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        const double z = lane_bcast(dvl, c) * s[c];
         s[c] = z;
 #pragma unroll
-        for (int c2 = c + 1; c2 < 16; ++c2) s[c2] -= dblk[c2][c] * z;
+        for (int c2 = c + 1; c2 < 16; ++c2) s[c2] -= lane_bcast(dr[c], c2) * z;
       }
 #pragma unroll
       for (int c = 0; c < 16; ++c) {
@@ -1667,53 +1748,53 @@ __global__ void __launch_bounds__(64) huge_solve_kernel(const UpdateArgs a_by_va
         slab[lane * LDZ + kb + c] = s[c];
       }
     }
-    __syncthreads();
+    HUGE_WAVE_SYNC();
+    HUGE_CLK(3);
   }
   if (lane < 16 && row0 + lane < I) a.hrowdot[(long long)I * h + row0 + lane] = rd;
-  for (int jb = rp - 16; jb >= 0; jb -= 16) {  // B := B inv(L)
-    double dl[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) dl[t] = H[(jb + n) + (long long)LD * (jb + g + 4 * t)];
+  issue_panel(rp - 16, rp - 16, rp, buf);
+  for (int jb = rp - 16; jb >= 0; jb -= 16, buf ^= 1) {  // B := B inv(L); panel = rows jb .. rp - 1 of the transposed copy
+    HUGE_CLK(4);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    HUGE_WAVE_SYNC();
+    HUGE_CLK(0);
+    if (jb >= 16) issue_panel(jb - 16, jb - 16, rp, buf ^ 1);
+    HUGE_CLK(1);
+    const double *lp = Lp + buf * PANEL;
     v4d acc;
 #pragma unroll
     for (int v = 0; v < 4; ++v) acc[v] = slab[(g + 4 * v) * LDZ + jb + n];
-    const double *hp = H + jb + n + (long long)LD * g;  // transposed copy: L[k + g][jb + n]
-    const double *zp = slab + n * LDZ + g;
-    for (int k = jb + 16; k < rp; k += 16) {
-      double bv[4], av[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        bv[u] = hp[(long long)LD * (k + 4 * u)];
-        av[u] = -zp[k + 4 * u];
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
-    }
+    acc = gemm(acc, lp + (16 + g) * 16 + n, jb + 16, rp);
 #pragma unroll
     for (int v = 0; v < 4; ++v) slab[(g + 4 * v) * LDZ + jb + n] = acc[v];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) dblk[n][g + 4 * t] = dl[t];
-    __syncthreads();
+    HUGE_WAVE_SYNC();
+    HUGE_CLK(2);
     if (lane < 16) {
-      double s[16];
+      double s[16], dr[16];
 #pragma unroll
-      for (int c = 0; c < 16; ++c) s[c] = slab[lane * LDZ + jb + c];
+      for (int c = 0; c < 16; ++c) {
+        s[c] = slab[lane * LDZ + jb + c];
+        dr[c] = lp[c * 16 + lane];  // L[jb + lane][jb + c]
+      }
+      const double dvl = dinv[jb + lane];
 #pragma unroll
       for (int j = 15; j >= 0; --j) {
         double sj = s[j];
 #pragma unroll
-        for (int k = j + 1; k < 16; ++k) sj -= dblk[k][j] * s[k];  // L[jb + k][jb + j]
-        s[j] = dinv[jb + j] * sj;
+        for (int k = j + 1; k < 16; ++k) sj -= lane_bcast(dr[j], k) * s[k];  // L[jb + k][jb + j]
+        s[j] = lane_bcast(dvl, j) * sj;
       }
 #pragma unroll
       for (int c = 0; c < 16; ++c) slab[lane * LDZ + jb + c] = s[c];
     }
-    __syncthreads();
+    HUGE_WAVE_SYNC();
+    HUGE_CLK(3);
   }
   for (int c0 = 0; c0 < rp; c0 += 4) {
     const int c = c0 + g;
     if (rok && c < r) fac[row0 + n + (long long)I * c] = (T)slab[n * LDZ + c];
   }
+  HUGE_CLK_DUMP(5, 8);  // CALS_DIAG: cycles in {wait for the panel, DMA issue, block part, triangle, rest}
 }
 
 // Column scales (Ktensor::normalize(mode, iteration)) and the normalisation, one wavefront per column; the jackknife
@@ -1804,37 +1885,65 @@ __global__ void __launch_bounds__(256) huge_gram_kernel(const UpdateArgs a_by_va
   }
 }
 
-// Fast error of the last mode (error::compute_fast_error) + the end-of-sweep rule.
-__global__ void __launch_bounds__(256) huge_error_kernel(const UpdateArgs a_by_value) {
+// Fast error of the last mode (error::compute_fast_error) + the end-of-sweep rule.  t2 = sum_ij lam_i lam_j prod_m
+// G_m[i][j]: wave = column j, lanes over i (coalesced, no index division; as e = tid, tid + 256, ... with i = e % r,
+// j = e / r on 256 threads this launch took 0.24 ms at rank 256).
+#define HUGE_ERR_THREADS 1024
+__global__ void __launch_bounds__(HUGE_ERR_THREADS) huge_error_kernel(const UpdateArgs a_by_value) {
   (void)a_by_value;
   HUGE_PROLOGUE();
+  constexpr int W = HUGE_ERR_THREADS / 64;
   const int jkf = (a.mt.jk_mode[slot] == a.mode) ? a.mt.jk_fiber[slot] : -1;
   const double *rowdot = a.rowdot ? a.rowdot + (long long)I * k_model : a.hrowdot + (long long)I * h;
-  __shared__ double redt[UPD_WAVES];
+  __shared__ double redt[W];
   double t3 = 0.0;
-  for (int i0 = tid; i0 < I; i0 += 2 * UPD_THREADS)
-#pragma unroll
-    for (int nn = 0; nn < 2; ++nn) {
-      const int i = i0 + nn * UPD_THREADS;
-      if (i < I && i != jkf) t3 += rowdot[i];
-    }
+  for (int i = tid; i < I; i += HUGE_ERR_THREADS)
+    if (i != jkf) t3 += rowdot[i];
   t3 = wave_sum(t3);
   if (lane == 0) redt[wave] = t3;
   __syncthreads();
-  t3 = redt[0] + redt[1] + redt[2] + redt[3];
+  t3 = 0.0;
+#pragma unroll
+  for (int w = 0; w < W; ++w) t3 += redt[w];
   __syncthreads();
   double t2 = 0.0;
-  for (int e = tid; e < r * r; e += UPD_THREADS) {
-    const int i = e % r, j = e / r;
-    double hh = 1.0;
-    for (int m = 0; m < a.n_modes; ++m) hh *= a.gram[m][i + CALS_GLD * (long long)(col + j)];
-    t2 += a.lambda[col + i] * a.lambda[col + j] * hh;
+  {
+    constexpr int NQ = CALS_GLD / 64, JB = 4;  // four columns' loads in flight (a round trip per column and mode otherwise)
+    double li[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) li[q] = (lane + 64 * q < r) ? a.lambda[col + lane + 64 * q] : 0.0;
+    for (int j0 = wave; j0 < r; j0 += W * JB) {
+      double hh[JB][NQ];
+#pragma unroll
+      for (int b = 0; b < JB; ++b)
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) hh[b][q] = 1.0;
+      for (int m = 0; m < a.n_modes; ++m) {
+        const double *gp = a.gram[m] + CALS_GLD * (long long)col + lane;
+#pragma unroll
+        for (int b = 0; b < JB; ++b) {
+          const int j = j0 + W * b;
+#pragma unroll
+          for (int q = 0; q < NQ; ++q)
+            hh[b][q] *= (j < r && lane + 64 * q < r) ? gp[CALS_GLD * (long long)j + 64 * q] : 0.0;
+        }
+      }
+#pragma unroll
+      for (int b = 0; b < JB; ++b) {
+        const int j = j0 + W * b;
+        const double lj = (j < r) ? a.lambda[col + j] : 0.0;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) t2 += li[q] * lj * hh[b][q];
+      }
+    }
   }
   t2 = wave_sum(t2);
   if (lane == 0) redt[wave] = t2;
   __syncthreads();
   if (tid == 0) {
-    t2 = redt[0] + redt[1] + redt[2] + redt[3];
+    t2 = 0.0;
+#pragma unroll
+    for (int w = 0; w < W; ++w) t2 += redt[w];
     const int jm = a.mt.jk_mode[slot];
     const double xn = (jm >= 0) ? a.jk_norms[a.mt.jk_fiber[slot]] : a.X_norm;
     const double e2 = fmax(xn * xn + t2 - 2.0 * t3, 0.0);
@@ -2045,13 +2154,17 @@ hipError_t update_launch(const UpdateArgs &a_in, int rmax_needed, hipStream_t st
     a.xld = 0;
     if (!a.rowdot) {
       hipLaunchKernelGGL(huge_hadamard_kernel, dim3(rp / 4, nh), dim3(256), 0, st, a);
-      hipLaunchKernelGGL(huge_potrf_kernel, dim3(1, nh), dim3(256), 0, st, a);
-      const size_t sdyn = (size_t)(16 * (rp + 4) + CALS_GLD + 16 * 17) * sizeof(double);
+      hipLaunchKernelGGL(huge_potrf_kernel, dim3(1, nh), dim3(HUGE_POTRF_THREADS), 0, st, a);
+      const size_t sdyn = (size_t)HUGE_SOLVE_LDS_DOUBLES(rp) * sizeof(double);
       const dim3 sgrid((a.I + 15) / 16, nh);
-      if (f32)
+      static AttrOnce s_f64, s_f32;
+      if (f32) {
+        if ((e = upd_raise_lds(&huge_solve_kernel<float>, s_f32, budget)) != hipSuccess) return e;
         hipLaunchKernelGGL(huge_solve_kernel<float>, sgrid, dim3(64), sdyn, st, a);
-      else
+      } else {
+        if ((e = upd_raise_lds(&huge_solve_kernel<double>, s_f64, budget)) != hipSuccess) return e;
         hipLaunchKernelGGL(huge_solve_kernel<double>, sgrid, dim3(64), sdyn, st, a);
+      }
     }
     if (f32) {
       hipLaunchKernelGGL(huge_scale_kernel<float>, dim3(rp / 4, nh), dim3(256), 0, st, a);
@@ -2060,7 +2173,7 @@ hipError_t update_launch(const UpdateArgs &a_in, int rmax_needed, hipStream_t st
       hipLaunchKernelGGL(huge_scale_kernel<double>, dim3(rp / 4, nh), dim3(256), 0, st, a);
       hipLaunchKernelGGL(huge_gram_kernel<double>, dim3(nt * (nt + 1) / 2, nh), dim3(256), 0, st, a);
     }
-    if (a.is_last) hipLaunchKernelGGL(huge_error_kernel, dim3(1, nh), dim3(256), 0, st, a);
+    if (a.is_last) hipLaunchKernelGGL(huge_error_kernel, dim3(1, nh), dim3(HUGE_ERR_THREADS), 0, st, a);
   }
   return hipGetLastError();
 }

@@ -1,4 +1,6 @@
-"""Diagnostics (CALS_DIAG build): phase timing of update_body_huge (mode 0) for ONE model of rank r at C3's shape."""
+"""Diagnostics (CALS_DIAG build): phase cycles of the rank > 64 update launches (mode 0) for ONE model of rank r at
+C3's shape -- huge_potrf_kernel's steps (a) / (b) / (c) and huge_solve_kernel's wait / DMA issue / block part /
+triangle / rest (workgroup 0), in shader-clock cycles summed over the kernel's blocks."""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -19,7 +21,7 @@ for r in [int(v) for v in sys.argv[1:]] or [65, 128, 256]:
     e.sweep(3); e.synchronize()
     buf = (C.c_uint64 * (16 * 2048))()
     e._chk(e.lib.cals_hip_debug_ttm_trace(e.h, buf, 16 * 2048))
-    t = np.frombuffer(buf, dtype=np.uint64).astype(np.int64)[16 * 2048 - 64:][:7]
-    names = ["hadamard", "cholesky", "row solves", "col stats", "scale pass", "gramian"]
-    print("rank", r, "update_body_huge phases (us @100 MHz memtime?):", ", ".join("%s %d" % (n, d) for n, d in zip(names, np.diff(t))), "| total", t[6] - t[0], flush=True)
+    t = np.frombuffer(buf, dtype=np.uint64).astype(np.int64)[16 * 2048 - 64:]
+    print("rank", r, "| potrf (a) tiles %d, (b) diagonal %d, (c) below + stores %d | solve: wait %d, DMA issue %d, block part %d, "
+          "triangle %d, rest %d" % tuple(t[[0, 1, 2, 8, 9, 10, 11, 12]]), flush=True)
     e.close()
