@@ -160,6 +160,8 @@ struct cals_hip_engine {
   size_t hscratch_blocks = 0;
   double *hrowdot = nullptr;   // ... and their rows' <z, z> (unconstrained update), [n_huge][I]
   size_t hrowdot_len = 0;
+  hipStream_t side_stream = nullptr;  // ... and their Hadamard + Cholesky launches, next to the mode's MTTKRP
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   double *nnls_hscratch = nullptr;  // ... and the blocks of nnls_huge_kernel
   size_t nnls_hblocks = 0;
   int *d_hcounter = nullptr;
@@ -261,16 +263,30 @@ void note_device_used(int device) {
   std::call_once(once, [] { std::atexit(drain_devices_at_exit); });
 }
 
+// hipMalloc; with CALS_POISON_ALLOC=1 (debugging) the new block is filled with 0xFF bytes first -- NaN as fp64 / fp32,
+// -1 as an index -- so that a kernel reading memory nobody wrote shows up in every run, not only when a recycled
+// block happens to hold harmful bits.  (Buffers the engine relies on being zero go through dev_alloc, which zeroes.)
+static hipError_t cals_malloc(void **p, size_t bytes) {
+  static const bool poison = getenv("CALS_POISON_ALLOC") != nullptr;
+  const hipError_t rc = hipMalloc(p, bytes);
+  if (rc == hipSuccess && poison) (void)hipMemset(*p, 0xFF, bytes);
+  return rc;
+}
+template <typename T>
+static hipError_t cals_malloc(T **p, size_t bytes) {
+  return cals_malloc(reinterpret_cast<void **>(p), bytes);
+}
+
 template <typename T>
 int dev_alloc(cals_hip_engine *e, T **p, size_t n) {
-  HIPCHK(hipMalloc((void **)p, std::max<size_t>(n, 1) * sizeof(T)));
+  HIPCHK(cals_malloc((void **)p, std::max<size_t>(n, 1) * sizeof(T)));
   HIPCHK(hipMemsetAsync(*p, 0, std::max<size_t>(n, 1) * sizeof(T), e->stream));
   return CALS_HIP_OK;
 }
 
 // zero-initialised buffer of n storage elements (double | float)
 int dev_alloc_elems(cals_hip_engine *e, void **p, size_t n) {
-  HIPCHK(hipMalloc(p, std::max<size_t>(n, 1) * e->es));
+  HIPCHK(cals_malloc(p, std::max<size_t>(n, 1) * e->es));
   HIPCHK(hipMemsetAsync(*p, 0, std::max<size_t>(n, 1) * e->es, e->stream));
   return CALS_HIP_OK;
 }
@@ -854,7 +870,7 @@ int sweep_once(cals_hip_engine *e, bool evict_enabled, bool defer_changed = fals
         if (e->nnls_hscratch) HIPCHK(hipFree(e->nnls_hscratch));
         e->nnls_hscratch = nullptr;
         e->nnls_hblocks = 0;
-        HIPCHK(hipMalloc((void **)&e->nnls_hscratch, need * nnls_huge_block_doubles() * sizeof(double)));
+        HIPCHK(cals_malloc((void **)&e->nnls_hscratch, need * nnls_huge_block_doubles() * sizeof(double)));
         e->nnls_hblocks = need;
       }
     }
@@ -866,7 +882,7 @@ int sweep_once(cals_hip_engine *e, bool evict_enabled, bool defer_changed = fals
         if (e->hrowdot) HIPCHK(hipFree(e->hrowdot));
         e->hrowdot = nullptr;
         e->hrowdot_len = 0;
-        HIPCHK(hipMalloc((void **)&e->hrowdot, (need + need / 2) * sizeof(double)));
+        HIPCHK(cals_malloc((void **)&e->hrowdot, (need + need / 2) * sizeof(double)));
         e->hrowdot_len = need + need / 2;
       }
     }
@@ -875,9 +891,9 @@ int sweep_once(cals_hip_engine *e, bool evict_enabled, bool defer_changed = fals
       if (e->hscratch) HIPCHK(hipFree(e->hscratch));
       e->hscratch = nullptr;
       e->hscratch_blocks = n_huge + n_huge / 2;
-      HIPCHK(hipMalloc((void **)&e->hscratch, e->hscratch_blocks * (size_t)CALS_GLD * CALS_GLD * sizeof(double)));
+      HIPCHK(cals_malloc((void **)&e->hscratch, e->hscratch_blocks * (size_t)CALS_GLD * CALS_GLD * sizeof(double)));
     }
-    if (!e->d_hcounter) HIPCHK(hipMalloc((void **)&e->d_hcounter, sizeof(int)));
+    if (!e->d_hcounter) HIPCHK(cals_malloc((void **)&e->d_hcounter, sizeof(int)));
   }
   if (e->sweep_log_on) {
     cals_hip_sweep_record rec{};
@@ -892,6 +908,39 @@ int sweep_once(cals_hip_engine *e, bool evict_enabled, bool defer_changed = fals
   for (int n = 0; n < e->n_modes; n++) {
     e->cur_mode = n;
     Geo g{0, 0};
+    UpdateArgs u{};
+    u.slots = e->d_slots;
+    u.n_slots = ns;
+    u.mt = e->mt;
+    u.factor = e->factor[n];
+    u.dtype = e->dtype;
+    u.I = (int)e->modes[n];
+    for (int m = 0; m < e->n_modes; m++) u.gram[m] = e->gram[m];
+    u.lambda = e->lambda;
+    u.n_modes = e->n_modes;
+    u.mode = n;
+    u.is_last = (n == e->n_modes - 1);
+    u.hscratch = e->hscratch;
+    u.hcounter = e->d_hcounter;
+    u.huge_idx = e->d_cls_idx + e->cls_off[5];  // the models above CALS_RMAX (class 5 of nnls_rank_class)
+    u.n_huge = e->cls_off[6] - e->cls_off[5];
+    u.hrowdot = e->hrowdot;
+    // Models above CALS_RMAX, unconstrained update: H of this mode (the other modes' Gramians) is final NOW, before
+    // this mode's MTTKRP -- its Hadamard product and Cholesky factor (one workgroup per model, 0.23 ms at rank 256)
+    // go to a side stream and run next to the MTTKRP (whose grid leaves a few CUs free) instead of after it.
+    bool pre_factored = false;
+    if ((upd_classes & 4) && e->prm.update_method != 1) {
+      if (!e->side_stream) {
+        HIPCHK(hipStreamCreateWithFlags(&e->side_stream, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
+      }
+      HIPCHK(hipEventRecord(e->ev_fork, e->stream));
+      HIPCHK(hipStreamWaitEvent(e->side_stream, e->ev_fork, 0));
+      HIPCHK(update_huge_factor_launch(u, rank_max, e->side_stream));
+      HIPCHK(hipEventRecord(e->ev_join, e->side_stream));
+      pre_factored = true;
+    }
     const bool by_contract = e->tree.on && e->tree.t_second == n;
     if (by_contract) {
       if ((rc = launch_contract(e, R, e->factor[n]))) return rc;
@@ -912,18 +961,6 @@ int sweep_once(cals_hip_engine *e, bool evict_enabled, bool defer_changed = fals
       return rc;
     }
     const bool g_in_place = by_contract || e->gp.on;  // G is already in the factor buffer
-    UpdateArgs u{};
-    u.slots = e->d_slots;
-    u.n_slots = ns;
-    u.mt = e->mt;
-    u.factor = e->factor[n];
-    u.dtype = e->dtype;
-    u.I = (int)e->modes[n];
-    for (int m = 0; m < e->n_modes; m++) u.gram[m] = e->gram[m];
-    u.lambda = e->lambda;
-    u.n_modes = e->n_modes;
-    u.mode = n;
-    u.is_last = (n == e->n_modes - 1);
     if (u.is_last && fin_in_update) {
       u.fin.on = 1;
       u.fin.max_iter = e->prm.max_iterations;
@@ -934,11 +971,10 @@ int sweep_once(cals_hip_engine *e, bool evict_enabled, bool defer_changed = fals
     u.X_norm = e->X_norm;
     u.jk_norms = e->d_jk_norms;
     u.dbg_trace = e->dbg_trace ? e->dbg_trace + 16 * 2048 - 64 : nullptr;  // last 64 entries of the trace
-    u.hscratch = e->hscratch;
-    u.hcounter = e->d_hcounter;
-    u.huge_idx = e->d_cls_idx + e->cls_off[5];  // the models above CALS_RMAX (class 5 of nnls_rank_class)
-    u.n_huge = e->cls_off[6] - e->cls_off[5];
-    u.hrowdot = e->hrowdot;
+    if (pre_factored) {
+      HIPCHK(hipStreamWaitEvent(e->stream, e->ev_join, 0));
+      u.huge_factored = 1;
+    }
     const int pk = prof_begin(e, 1, 0, LOG_UPDATE);
     // The update bodies for ranks <= CALS_RFAST sum the split-K partial tiles of their model's columns themselves
     // (UpdateArgs::partial): no reduce launch, no round trip of G through the factor buffer.  The NNLS kernel and
@@ -1080,7 +1116,7 @@ int fetch_status(cals_hip_engine *e) {
     if (e->h_status) HIPCHK(hipHostFree(e->h_status));
     e->d_status = e->h_status = nullptr;
     e->status_cap = std::max<size_t>(2 * (ns + 1), 256);
-    HIPCHK(hipMalloc((void **)&e->d_status, e->status_cap * sizeof(StatusRec)));
+    HIPCHK(cals_malloc((void **)&e->d_status, e->status_cap * sizeof(StatusRec)));
     HIPCHK(hipHostMalloc((void **)&e->h_status, e->status_cap * sizeof(StatusRec), hipHostMallocDefault));
   }
   HIPCHK(pack_status_launch(e->d_slots, (int)ns, e->mt, e->changed_deferred ? e->tree.d_changed : nullptr,
@@ -1114,13 +1150,13 @@ int ensure_col_scratch(cals_hip_engine *e, size_t words, size_t n_idx) {
     if (e->col_scratch) HIPCHK(hipFree(e->col_scratch));
     e->col_scratch = nullptr;
     e->col_scratch_words = words + words / 2;
-    HIPCHK(hipMalloc((void **)&e->col_scratch, e->col_scratch_words * sizeof(unsigned)));
+    HIPCHK(cals_malloc((void **)&e->col_scratch, e->col_scratch_words * sizeof(unsigned)));
   }
   if (n_idx > e->colidx_cap) {
     if (e->d_colidx) HIPCHK(hipFree(e->d_colidx));
     e->d_colidx = nullptr;
     e->colidx_cap = std::max<size_t>(2 * n_idx, 4096);
-    HIPCHK(hipMalloc((void **)&e->d_colidx, e->colidx_cap * sizeof(int)));
+    HIPCHK(cals_malloc((void **)&e->d_colidx, e->colidx_cap * sizeof(int)));
   }
   return CALS_HIP_OK;
 }
@@ -1714,7 +1750,7 @@ int cals_hip_create_ex(cals_hip_engine **out, int n_modes, const int64_t *modes,
       pt_elems = std::max(pt_elems, nb_max * (size_t)L.Ap * CALS_BN);
     }
     if ((rc = dev_alloc_elems(e, &tp.Pt, pt_elems))) return rc;
-    if (hipMalloc(&tp.Tbuf, t_elems * e->es) != hipSuccess) {
+    if (cals_malloc(&tp.Tbuf, t_elems * e->es) != hipSuccess) {
       (void)hipGetLastError();
       tp.Tbuf = nullptr;
       return fail(e, CALS_HIP_ERR_HIP,
@@ -1882,6 +1918,11 @@ int cals_hip_destroy(cals_hip_engine *e) {
   fr(e->partial);
   fr(e->hscratch);
   fr(e->hrowdot);
+  if (e->side_stream) {
+    (void)hipStreamDestroy(e->side_stream);
+    (void)hipEventDestroy(e->ev_fork);
+    (void)hipEventDestroy(e->ev_join);
+  }
   fr(e->nnls_hscratch);
   fr(e->d_hcounter);
   fr(e->tree.Tbuf);
@@ -1934,7 +1975,7 @@ int set_tensor_impl(cals_hip_engine *e, const void *X_host, int src_dtype) {
   for (int n = 0; n < e->n_modes; n++) total *= e->modes[n];
   const size_t src_es = (src_dtype == CALS_F32) ? sizeof(float) : sizeof(double);
   void *dX = nullptr;
-  HIPCHK(hipMalloc(&dX, (size_t)total * src_es));
+  HIPCHK(cals_malloc(&dX, (size_t)total * src_es));
   HIPCHK(hipMemcpyAsync(dX, X_host, (size_t)total * src_es, hipMemcpyHostToDevice, e->stream));
   int dims[CALS_HIP_MAX_MODES];
   for (int n = 0; n < e->n_modes; n++) dims[n] = (int)e->modes[n];
@@ -1945,7 +1986,7 @@ int set_tensor_impl(cals_hip_engine *e, const void *X_host, int src_dtype) {
       L.Xp = nullptr;
     }
     const size_t elems = (size_t)L.Mp * (size_t)L.Ap * (size_t)L.S;
-    HIPCHK(hipMalloc((void **)&L.Xp, elems * e->es));
+    HIPCHK(cals_malloc((void **)&L.Xp, elems * e->es));
     HIPCHK(permute_pad_launch(dX, src_dtype, e->n_modes, dims, n, L.a_mode, L.Mp, L.Ap, L.Xp,
                               e->dtype, L.S, e->stream));
   }
@@ -1973,15 +2014,15 @@ int set_tensor_impl(cals_hip_engine *e, const void *X_host, int src_dtype) {
       vdims[nv++] = (int)e->gp.rows[1];
     }
     const size_t elems = (size_t)L.Mp * (size_t)L.Ap * (size_t)L.S;
-    HIPCHK(hipMalloc((void **)&L.Xp, elems * e->es));
+    HIPCHK(cals_malloc((void **)&L.Xp, elems * e->es));
     HIPCHK(permute_pad_launch(dX, src_dtype, nv, vdims, vm, va, L.Mp, L.Ap, L.Xp, e->dtype, L.S, e->stream));
   }
   // ||X|| and the jackknife norms from the mode-0 slice sums of squares
   const long long I = e->modes[0], cols = total / I;
   const int n_part = 256;
   double *d_part = nullptr, *d_ss = nullptr;
-  HIPCHK(hipMalloc((void **)&d_part, (size_t)n_part * (size_t)I * sizeof(double)));
-  HIPCHK(hipMalloc((void **)&d_ss, (size_t)I * sizeof(double)));
+  HIPCHK(cals_malloc((void **)&d_part, (size_t)n_part * (size_t)I * sizeof(double)));
+  HIPCHK(cals_malloc((void **)&d_ss, (size_t)I * sizeof(double)));
   HIPCHK(slice_sumsq_launch(dX, src_dtype, I, cols, d_part, n_part, d_ss, e->stream));
   std::vector<double> ss((size_t)I);
   HIPCHK(hipMemcpyAsync(ss.data(), d_ss, (size_t)I * sizeof(double), hipMemcpyDeviceToHost,
@@ -2254,7 +2295,7 @@ int cals_hip_debug_mttkrp(cals_hip_engine *e, int mode, double *G_host) {
     int rc = launch_group_t(e, mode < e->gp.h ? 0 : 1, R);
     if (rc) return rc;
     void *scratch = nullptr;
-    HIPCHK(hipMalloc(&scratch, (size_t)(I * R) * e->es));
+    HIPCHK(cals_malloc(&scratch, (size_t)(I * R) * e->es));
     rc = launch_group_contract(e, mode, R, scratch);
     if (rc) {
       (void)hipFree(scratch);
@@ -2295,7 +2336,7 @@ int cals_hip_debug_mttkrp_path(cals_hip_engine *e, int mode, int path, double *G
     const int64_t I = e->modes[mode];
     if ((rc = launch_ttm(e, (mode + 2) % 3, R, &g))) return rc;
     void *scratch = nullptr;
-    HIPCHK(hipMalloc(&scratch, (size_t)(I * R) * e->es));
+    HIPCHK(cals_malloc(&scratch, (size_t)(I * R) * e->es));
     rc = launch_contract(e, R, scratch);
     tree_invalidate(e);
     if (rc) return rc;

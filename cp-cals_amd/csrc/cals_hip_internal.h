@@ -181,10 +181,14 @@ struct UpdateArgs {
   const int *huge_idx;
   int n_huge;
   double *hrowdot;
+  int huge_factored;   // update_huge_factor_launch already ran for this mode (on a side stream, next to the MTTKRP)
 };
 // classes: bit 0 = models of rank <= CALS_RFAST in flight, bit 1 = ranks 33..CALS_RMAX, bit 2 = above (0 = unknown:
 // every kernel)
 hipError_t update_launch(const UpdateArgs &a, int rmax_needed, hipStream_t st, int classes = 0);
+// H = hadamard of the other modes' Gramians + its Cholesky factor for the models above CALS_RMAX: the part of their
+// update that does not depend on the mode's MTTKRP (then UpdateArgs::huge_factored = 1 for update_launch)
+hipError_t update_huge_factor_launch(const UpdateArgs &a, int rmax_needed, hipStream_t st);
 
 // update::update_factor_non_negative_constrained for one mode (nnls_kernel.hip)
 struct NnlsArgs {

@@ -2100,6 +2100,14 @@ static hipError_t upd_raise_lds(K kernel, AttrOnce &once, size_t budget) {
   });
 }
 
+hipError_t update_huge_factor_launch(const UpdateArgs &a, int rmax_needed, hipStream_t st) {
+  if (!a.huge_idx || a.n_huge <= 0 || !a.hscratch) return hipErrorInvalidValue;
+  const int rp = std::min((rmax_needed + 15) & ~15, CALS_GLD);
+  hipLaunchKernelGGL(huge_hadamard_kernel, dim3(rp / 4, (unsigned)a.n_huge), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(huge_potrf_kernel, dim3(1, (unsigned)a.n_huge), dim3(HUGE_POTRF_THREADS), 0, st, a);
+  return hipGetLastError();
+}
+
 // rank_small / rank_big: are there models of rank <= CALS_RFAST / above it in flight (both unknown -> both launched)
 hipError_t update_launch(const UpdateArgs &a_in, int rmax_needed, hipStream_t st, int classes) {
   if (a_in.n_slots <= 0) return hipSuccess;
@@ -2153,8 +2161,7 @@ hipError_t update_launch(const UpdateArgs &a_in, int rmax_needed, hipStream_t st
     const unsigned nh = (unsigned)a.n_huge;
     a.xld = 0;
     if (!a.rowdot) {
-      hipLaunchKernelGGL(huge_hadamard_kernel, dim3(rp / 4, nh), dim3(256), 0, st, a);
-      hipLaunchKernelGGL(huge_potrf_kernel, dim3(1, nh), dim3(HUGE_POTRF_THREADS), 0, st, a);
+      if (!a.huge_factored && (e = update_huge_factor_launch(a, rmax_needed, st)) != hipSuccess) return e;
       const size_t sdyn = (size_t)HUGE_SOLVE_LDS_DOUBLES(rp) * sizeof(double);
       const dim3 sgrid((a.I + 15) / 16, nh);
       static AttrOnce s_f64, s_f32;

@@ -56,6 +56,10 @@ hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) {
   std::memmove(d, s, n);
   return hipSuccess;
 }
+hipError_t hipMemset(void *d, int v, size_t n) {
+  std::memset(d, v, n);
+  return hipSuccess;
+}
 hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t) {
   std::memset(d, v, n);
   return hipSuccess;
@@ -64,6 +68,8 @@ hipError_t hipStreamCreate(hipStream_t *s) {
   *s = reinterpret_cast<hipStream_t>(std::malloc(8));
   return hipSuccess;
 }
+hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { return hipStreamCreate(s); }
+hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 hipError_t hipStreamDestroy(hipStream_t s) {
   std::free(s);
   return hipSuccess;
@@ -125,6 +131,7 @@ hipError_t update_launch(const UpdateArgs &a, int, hipStream_t st, int) {
   f.evict_enabled = a.fin.evict_enabled;
   return finish_launch(f, st);
 }
+hipError_t update_huge_factor_launch(const UpdateArgs &, int, hipStream_t) { return hipSuccess; }
 hipError_t nnls_launch(const NnlsArgs &, hipStream_t) { return hipSuccess; }
 int nnls_rank_class(int r) { return r <= 16 ? 0 : r <= 24 ? 1 : r <= 32 ? 2 : r <= 48 ? 3 : r <= CALS_RMAX ? 4 : 5; }
 size_t nnls_huge_block_doubles() { return (size_t)CALS_GLD * CALS_GLD * 9; }
