@@ -1,10 +1,13 @@
 """Condense rocprofv3 CSV output (kernel trace / counter collection) into a small text summary
-for profiles/.  Usage: python tools/rocprof_summary.py <rocprof output dir> [<label>]"""
+for profiles/.  Usage: python tools/rocprof_summary.py <rocprof output dir> [<label>]
+(ROCPROF_SUMMARY_TOP=N: list the N longest kernels instead of 12)"""
 import csv
 import glob
 import os
 import sys
 from collections import defaultdict
+
+TOP = int(os.environ.get("ROCPROF_SUMMARY_TOP", "12"))
 
 
 def main():
@@ -14,7 +17,7 @@ def main():
     for f in sorted(glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True)):
         print("\n## kernel stats (%s)" % os.path.basename(f))
         rows = list(csv.DictReader(open(f)))
-        for r in rows[:12]:
+        for r in rows[:TOP]:
             print("  %-60s calls=%-6s total_ns=%-14s avg_ns=%-12s pct=%s" % (
                 r.get("Name", "")[:60], r.get("Calls"), r.get("TotalDurationNs"),
                 r.get("AverageNs"), r.get("Percentage")))
@@ -29,7 +32,7 @@ def main():
             a[2] = (r.get("VGPR_Count"), r.get("Accum_VGPR_Count"), r.get("SGPR_Count"),
                     r.get("LDS_Block_Size"), r.get("Workgroup_Size"), r.get("Grid_Size"))
         print("\n## kernel trace (%s): per-kernel launches, average duration" % os.path.basename(f))
-        for k, (n, t, regs) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:12]:
+        for k, (n, t, regs) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:TOP]:
             print("  %-60s n=%-5d avg_us=%-10.2f total_ms=%-10.3f vgpr/agpr/sgpr/lds/wg/grid=%s" % (
                 k[:60], n, t / n * 1e-3, t * 1e-6, regs))
     for f in sorted(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)):
