@@ -864,7 +864,7 @@ int sweep_once(cals_hip_engine *e, bool evict_enabled, bool defer_changed = fals
   if (n_huge) {
     if (e->prm.update_method == 1) {  // nnls_huge_kernel: H and the waves' Cholesky factors, per workgroup
       int chunks = 1;
-      for (int n = 0; n < e->n_modes; n++) chunks = std::max(chunks, nnls_huge_chunks((int)e->modes[n]));
+      for (int n = 0; n < e->n_modes; n++) chunks = std::max(chunks, nnls_huge_chunks((int)e->modes[n], (int)n_huge));
       const size_t need = n_huge * (size_t)chunks;
       if (need > e->nnls_hblocks) {
         if (e->nnls_hscratch) HIPCHK(hipFree(e->nnls_hscratch));

@@ -215,13 +215,13 @@ struct NnlsArgs {
   int rlo, rhi;        // set by nnls_launch: the ranks this launch serves
   int chunks;          // set by nnls_launch: workgroups per model
   unsigned long long *dbg_counts;  // CALS_DIAG builds: {rows, solves, factorisations, main-loop passes, inner passes}
-  double *hscratch;    // models above CALS_RMAX: n_huge * nnls_huge_chunks(I) blocks of nnls_huge_block_doubles()
+  double *hscratch;    // models above CALS_RMAX: n_huge * nnls_huge_chunks(I, n_huge) blocks of nnls_huge_block_doubles()
   int *hcounter;       // zero at launch: blocks are handed out in arrival order
 };
 hipError_t nnls_launch(const NnlsArgs &a, hipStream_t st);
 int nnls_rank_class(int r);  // 0: <= 16, 1: <= 24, 2: <= 32, 3: <= 48, 4: <= 64, 5: above (nnls_huge_kernel)
 size_t nnls_huge_block_doubles();
-int nnls_huge_chunks(int I);
+int nnls_huge_chunks(int I, int n_huge);
 struct NnlsResetArgs {
   unsigned long long *act[CALS_MAX_MODES];
   int I[CALS_MAX_MODES];

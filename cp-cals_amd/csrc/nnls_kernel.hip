@@ -1014,7 +1014,16 @@ __device__ __forceinline__ void multipliers_huge(const double *Hs, int r, HugeWa
 size_t nnls_huge_block_doubles() {
   return (size_t)CALS_GLD * CALS_GLD * (1 + 2 * NNLS_HWAVES);
 }
-int nnls_huge_chunks(int I) { return std::max(1, std::min((I + 4 * NNLS_HWAVES - 1) / (4 * NNLS_HWAVES), 16)); }
+// Workgroups per model of rank > CALS_RMAX: ONE ROW PER WAVEFRONT where the scratch budget allows it (a row of such
+// a model refactors passive blocks of up to 256 x 256 per exchange -- 25 ms of one wave at rank 256 -- and the rows
+// of a mode are all the parallelism there is: with 16 workgroups a wave worked through five rows in turn).
+// n_huge models share at most 16 GiB of factor scratch (4.7 MB per workgroup).
+int nnls_huge_chunks(int I, int n_huge) {
+  const size_t block_bytes = nnls_huge_block_doubles() * sizeof(double);
+  const size_t by_budget = ((size_t)16 << 30) / (block_bytes * (size_t)std::max(n_huge, 1));
+  const int want = (I + NNLS_HWAVES - 1) / NNLS_HWAVES;
+  return std::max(1, std::min(want, (int)std::min<size_t>(std::max<size_t>(by_budget, 1), 1024)));
+}
 
 template <typename T>
 __global__ void __launch_bounds__(64 * NNLS_HWAVES) nnls_huge_kernel(const NnlsArgs a) {
@@ -1323,7 +1332,7 @@ hipError_t nnls_launch(const NnlsArgs &a_in, hipStream_t st) {
       a.idx = a_in.cls_idx + a_in.cls_off[5];
     }
     a.n_cls = n_models;
-    a.chunks = nnls_huge_chunks(a.I);
+    a.chunks = nnls_huge_chunks(a.I, std::max(n_models, 1));
     const dim3 hgrid((unsigned)(std::max(n_models, 1) * a.chunks)), hblock(64 * NNLS_HWAVES);
     if (di)
       hipLaunchKernelGGL(nnls_huge_kernel<float>, hgrid, hblock, 0, st, a);

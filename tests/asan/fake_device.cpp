@@ -135,7 +135,7 @@ hipError_t update_huge_factor_launch(const UpdateArgs &, int, hipStream_t) { ret
 hipError_t nnls_launch(const NnlsArgs &, hipStream_t) { return hipSuccess; }
 int nnls_rank_class(int r) { return r <= 16 ? 0 : r <= 24 ? 1 : r <= 32 ? 2 : r <= 48 ? 3 : r <= CALS_RMAX ? 4 : 5; }
 size_t nnls_huge_block_doubles() { return (size_t)CALS_GLD * CALS_GLD * 9; }
-int nnls_huge_chunks(int I) { return I < 16 ? 1 : (I + 15) / 16 > 16 ? 16 : (I + 15) / 16; }
+int nnls_huge_chunks(int I, int) { return I < 16 ? 1 : (I + 15) / 16 > 16 ? 16 : (I + 15) / 16; }
 hipError_t nnls_reset_launch(const int *, int, const NnlsResetArgs &, hipStream_t) { return hipSuccess; }
 hipError_t reduce_partials_launch(const void *, int, int, int, int, void *, int, hipStream_t) { return hipSuccess; }
 hipError_t reduce_partials_scatter_launch(const void *, int, int, int, int, void *, const int *, int, hipStream_t) {
