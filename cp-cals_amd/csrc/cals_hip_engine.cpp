@@ -929,7 +929,9 @@ int sweep_once(cals_hip_engine *e, bool evict_enabled, bool defer_changed = fals
     // this mode's MTTKRP -- its Hadamard product and Cholesky factor (one workgroup per model, 0.23 ms at rank 256)
     // go to a side stream and run next to the MTTKRP (whose grid leaves a few CUs free) instead of after it.
     bool pre_factored = false;
-    if ((upd_classes & 4) && e->prm.update_method != 1) {
+    u.dbg_trace = e->dbg_trace ? e->dbg_trace + 16 * 2048 - 64 : nullptr;  // last 64 entries of the trace
+    static const bool no_side = getenv("CALS_HUGE_NO_SIDE") != nullptr;  // A/B switch: factor on the main stream
+    if ((upd_classes & 4) && e->prm.update_method != 1 && !no_side) {
       if (!e->side_stream) {
         HIPCHK(hipStreamCreateWithFlags(&e->side_stream, hipStreamNonBlocking));
         HIPCHK(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
@@ -970,7 +972,6 @@ int sweep_once(cals_hip_engine *e, bool evict_enabled, bool defer_changed = fals
     }
     u.X_norm = e->X_norm;
     u.jk_norms = e->d_jk_norms;
-    u.dbg_trace = e->dbg_trace ? e->dbg_trace + 16 * 2048 - 64 : nullptr;  // last 64 entries of the trace
     if (pre_factored) {
       HIPCHK(hipStreamWaitEvent(e->stream, e->ev_join, 0));
       u.huge_factored = 1;

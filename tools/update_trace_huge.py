@@ -6,6 +6,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 os.environ["CALS_TTM_TRACE"] = "1"
+os.environ["CALS_HUGE_NO_SIDE"] = "1"  # the factor launches alone on the main stream, not next to the MTTKRP
 import ctypes as C
 import cp_cals_amd as cc
 from cp_cals_amd import inputs
