@@ -267,7 +267,10 @@ int64_t cals_hip_host_active_cols(const int64_t *occupancy, int64_t n_cols);
 int cals_hip_set_profiling(cals_hip_engine *e, int level);
 int cals_hip_get_kernel_stats(cals_hip_engine *e, cals_hip_kernel_stats *out);
 int cals_hip_reset_kernel_stats(cals_hip_engine *e);
-/* hipStream_t the engine launches on (as void*), so callers can bracket it with their own events */
+/* hipStream_t the engine launches on (as void*), so callers can bracket it with their own events.  (While models of
+ * rank > 64 are in flight the engine forks two launches per mode -- their Hadamard product and Cholesky factor -- to
+ * an internal side stream and joins them back into this one by an event before they are needed: work recorded on
+ * this stream still brackets everything.) */
 void *cals_hip_stream(cals_hip_engine *e);
 /* Per-sweep log for CalsReport's timer matrices: on = an event pair around every launch (profiling
  * level 1) and one record per sweep; get returns the number of records (copies at most max_records). */
