@@ -855,13 +855,23 @@ int sweep_once(cals_hip_engine *e, bool evict_enabled, bool defer_changed = fals
   size_t n_huge = 0;  // models above CALS_RMAX: the update needs a global H / L block each
   unsigned rank_classes = 0;  // which LDS size classes of the NNLS kernel are in flight
   int upd_classes = 0;        // update kernels to launch: bit 0 = ranks <= CALS_RFAST, bit 1 = 33..CALS_RMAX, bit 2 = above
+  // The unconstrained update of the larger ranks is a pipeline of multi-workgroup launches (update_launch): from rank
+  // pipe_from on -- a boundary of the rank classes, so that the class list doubles as the pipeline's model list.
+  // (After update::NNLS only ranks > CALS_RMAX take it: the solved-row tail of the one-workgroup body is short.)
+  static const int huge_from_env = getenv("CALS_HUGE_FROM") ? atoi(getenv("CALS_HUGE_FROM")) : 0;  // experiments: 33 | 49 | 65
+  const int pipe_from = (e->prm.update_method == 1) ? CALS_RMAX + 1
+                        : (huge_from_env == 33 || huge_from_env == 49 || huge_from_env == 65) ? huge_from_env : CALS_HUGE_FROM_DEFAULT;
+  const int pipe_class = pipe_from == 33 ? 3 : pipe_from == 49 ? 4 : 5;
+  size_t n_pipe = 0;
   for (auto t : e->registry) {
-    rank_max = std::max(rank_max, (int)e->models[t].rank);
-    upd_classes |= (e->models[t].rank <= CALS_RFAST) ? 1 : (e->models[t].rank <= CALS_RMAX) ? 2 : 4;
-    if (e->models[t].rank > CALS_RMAX) n_huge++;
-    rank_classes |= 1u << nnls_rank_class((int)e->models[t].rank);
+    const int rk = (int)e->models[t].rank;
+    rank_max = std::max(rank_max, rk);
+    upd_classes |= (rk <= CALS_RFAST) ? 1 : (rk < pipe_from) ? 2 : 4;
+    if (rk > CALS_RMAX) n_huge++;
+    if (rk >= pipe_from) n_pipe++;
+    rank_classes |= 1u << nnls_rank_class(rk);
   }
-  if (n_huge) {
+  if (n_huge || n_pipe) {
     if (e->prm.update_method == 1) {  // nnls_huge_kernel: H and the waves' Cholesky factors, per workgroup
       int chunks = 1;
       for (int n = 0; n < e->n_modes; n++) chunks = std::max(chunks, nnls_huge_chunks((int)e->modes[n], (int)n_huge));
@@ -874,10 +884,10 @@ int sweep_once(cals_hip_engine *e, bool evict_enabled, bool defer_changed = fals
         e->nnls_hblocks = need;
       }
     }
-    if (e->prm.update_method != 1) {  // huge_solve_kernel's <z, z> per row, [n_huge][I]
+    if (e->prm.update_method != 1) {  // huge_solve_kernel's <z, z> per row, [n_pipe][I]
       int64_t imax = 1;
       for (int n = 0; n < e->n_modes; n++) imax = std::max(imax, e->modes[n]);
-      const size_t need = n_huge * (size_t)imax;
+      const size_t need = n_pipe * (size_t)imax;
       if (need > e->hrowdot_len) {
         if (e->hrowdot) HIPCHK(hipFree(e->hrowdot));
         e->hrowdot = nullptr;
@@ -887,10 +897,11 @@ int sweep_once(cals_hip_engine *e, bool evict_enabled, bool defer_changed = fals
       }
     }
     if (e->prm.line_search && e->prm.line_search_method != 0) n_huge *= 2;  // H and one Gramian at a time
-    if (n_huge > e->hscratch_blocks) {
+    const size_t n_blocks = std::max(n_huge, n_pipe);  // (the pipeline: one H / L block per model)
+    if (n_blocks > e->hscratch_blocks) {
       if (e->hscratch) HIPCHK(hipFree(e->hscratch));
       e->hscratch = nullptr;
-      e->hscratch_blocks = n_huge + n_huge / 2;
+      e->hscratch_blocks = n_blocks + n_blocks / 2;
       HIPCHK(cals_malloc((void **)&e->hscratch, e->hscratch_blocks * (size_t)CALS_GLD * CALS_GLD * sizeof(double)));
     }
     if (!e->d_hcounter) HIPCHK(cals_malloc((void **)&e->d_hcounter, sizeof(int)));
@@ -922,8 +933,9 @@ int sweep_once(cals_hip_engine *e, bool evict_enabled, bool defer_changed = fals
     u.is_last = (n == e->n_modes - 1);
     u.hscratch = e->hscratch;
     u.hcounter = e->d_hcounter;
-    u.huge_idx = e->d_cls_idx + e->cls_off[5];  // the models above CALS_RMAX (class 5 of nnls_rank_class)
-    u.n_huge = e->cls_off[6] - e->cls_off[5];
+    u.huge_idx = e->d_cls_idx + e->cls_off[pipe_class];  // the models of rank >= pipe_from (classes of nnls_rank_class)
+    u.n_huge = e->cls_off[6] - e->cls_off[pipe_class];
+    u.huge_from = pipe_from;
     u.hrowdot = e->hrowdot;
     // Models above CALS_RMAX, unconstrained update: H of this mode (the other modes' Gramians) is final NOW, before
     // this mode's MTTKRP -- its Hadamard product and Cholesky factor (one workgroup per model, 0.23 ms at rank 256)

@@ -135,6 +135,8 @@ struct ModelTable {
   int *flags;          // bit0: extrapolated this sweep, bit1: reversed this sweep, bit2: evict
 };
 
+// smallest rank whose unconstrained update runs as the pipeline of huge_* launches (33 | 49 | 65; measured)
+#define CALS_HUGE_FROM_DEFAULT 33
 struct UpdateArgs {
   const int *slots;    // active slots, one wave each
   int n_slots;
@@ -180,10 +182,11 @@ struct UpdateArgs {
   // hrowdot: [n_huge][I], written by the solve launch when rowdot is nullptr (unconstrained update).
   const int *huge_idx;
   int n_huge;
+  int huge_from;       // smallest rank the pipeline takes (33 | 49 | CALS_RMAX + 1; 0 = CALS_RMAX + 1)
   double *hrowdot;
   int huge_factored;   // update_huge_factor_launch already ran for this mode (on a side stream, next to the MTTKRP)
 };
-// classes: bit 0 = models of rank <= CALS_RFAST in flight, bit 1 = ranks 33..CALS_RMAX, bit 2 = above (0 = unknown:
+// classes: bit 0 = models of rank <= CALS_RFAST in flight, bit 1 = ranks 33..huge_from - 1, bit 2 = above (0 = unknown:
 // every kernel)
 hipError_t update_launch(const UpdateArgs &a, int rmax_needed, hipStream_t st, int classes = 0);
 // H = hadamard of the other modes' Gramians + its Cholesky factor for the models above CALS_RMAX: the part of their

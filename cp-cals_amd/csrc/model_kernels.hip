@@ -908,7 +908,10 @@ __device__ __forceinline__ v4d gramian_tile_b8(PTR panel, int row0, int row1, lo
   return acc;
 }
 
-// Ranks 33..CALS_RMAX (64): too wide for the register-resident bodies above; H / L (64 columns, ld 66: the
+// Ranks 33..CALS_RMAX (64) -- since the end of round 3 only their TAIL after update::NNLS (solved rows): the
+// unconstrained update of every rank above CALS_RFAST is the pipeline of huge_* launches below (CALS_HUGE_FROM_DEFAULT;
+// CALS_HUGE_FROM=49|65 in the environment brings this body back for A/B).
+// Too wide for the register-resident bodies above; H / L (64 columns, ld 66: the
 // transposed-copy stores of a wave spread over 16 banks instead of one) live in dynamic LDS and the rows are solved
 // through the factor panel itself, one row per thread, SIXTEEN COLUMNS AT A TIME in registers:
 //   * dpotf2 on the whole workgroup (thread = row; column j needs sum_{k<j} L[i][k] L[j][k]: own row over the
@@ -1409,13 +1412,14 @@ __global__ void __launch_bounds__(UPD_THREADS, 1) update_huge_kernel(const Updat
   __shared__ UpdShared sh;
   const int slot = a.slots[blockIdx.x];
   const int r = a.mt.rank[slot];
-  if (r <= CALS_RFAST || r > CALS_RMAX) return;  // above CALS_RMAX: the huge_* launches (update_launch)
+  const int huge_from = a.huge_from ? a.huge_from : CALS_RMAX + 1;
+  if (r <= CALS_RFAST || r > CALS_RMAX || (r >= huge_from && !a.rowdot)) return;  // the huge_* launches' models (update_launch)
   update_body_huge<T>(a_ptr, slot, r, sh);
 }
 #undef UPD_DISPATCH
 
 // ---------------------------------------------------------------------------------------------
-// Ranks 65..CALS_GLD (round 3): the update of such a model as a PIPELINE OF LAUNCHES, each spread over as many
+// Ranks 33..CALS_GLD (round 3): the update of such a model as a PIPELINE OF LAUNCHES, each spread over as many
 // workgroups as its step has independent pieces.  update_body_huge<T, false> ran the whole update on ONE workgroup:
 // 2.6 ms per mode for a rank-256 model at C3's shape (Hadamard 0.22, Cholesky 0.42, row solves 1.23 -- 300 rows on
 // 256 threads, 131 k dependent FMAs each --, scales 0.18, Gramian 0.57), all of it on the critical path of a sweep.

@@ -268,7 +268,7 @@ int cals_hip_set_profiling(cals_hip_engine *e, int level);
 int cals_hip_get_kernel_stats(cals_hip_engine *e, cals_hip_kernel_stats *out);
 int cals_hip_reset_kernel_stats(cals_hip_engine *e);
 /* hipStream_t the engine launches on (as void*), so callers can bracket it with their own events.  (While models of
- * rank > 64 are in flight the engine forks two launches per mode -- their Hadamard product and Cholesky factor -- to
+ * rank > 32 are in flight the engine forks two launches per mode -- their Hadamard product and Cholesky factor -- to
  * an internal side stream and joins them back into this one by an event before they are needed: work recorded on
  * this stream still brackets everything.) */
 void *cals_hip_stream(cals_hip_engine *e);
