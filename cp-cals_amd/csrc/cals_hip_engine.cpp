@@ -857,10 +857,9 @@ int sweep_once(cals_hip_engine *e, bool evict_enabled, bool defer_changed = fals
   int upd_classes = 0;        // update kernels to launch: bit 0 = ranks <= CALS_RFAST, bit 1 = 33..CALS_RMAX, bit 2 = above
   // The unconstrained update of the larger ranks is a pipeline of multi-workgroup launches (update_launch): from rank
   // pipe_from on -- a boundary of the rank classes, so that the class list doubles as the pipeline's model list.
-  // (After update::NNLS only ranks > CALS_RMAX take it: the solved-row tail of the one-workgroup body is short.)
+  // (After update::NNLS the pipeline is its tail: scales, Gramian, error.)
   static const int huge_from_env = getenv("CALS_HUGE_FROM") ? atoi(getenv("CALS_HUGE_FROM")) : 0;  // experiments: 33 | 49 | 65
-  const int pipe_from = (e->prm.update_method == 1) ? CALS_RMAX + 1
-                        : (huge_from_env == 33 || huge_from_env == 49 || huge_from_env == 65) ? huge_from_env : CALS_HUGE_FROM_DEFAULT;
+  const int pipe_from = (huge_from_env == 33 || huge_from_env == 49 || huge_from_env == 65) ? huge_from_env : CALS_HUGE_FROM_DEFAULT;
   const int pipe_class = pipe_from == 33 ? 3 : pipe_from == 49 ? 4 : 5;
   size_t n_pipe = 0;
   for (auto t : e->registry) {

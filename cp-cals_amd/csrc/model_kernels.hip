@@ -908,9 +908,8 @@ __device__ __forceinline__ v4d gramian_tile_b8(PTR panel, int row0, int row1, lo
   return acc;
 }
 
-// Ranks 33..CALS_RMAX (64) -- since the end of round 3 only their TAIL after update::NNLS (solved rows): the
-// unconstrained update of every rank above CALS_RFAST is the pipeline of huge_* launches below (CALS_HUGE_FROM_DEFAULT;
-// CALS_HUGE_FROM=49|65 in the environment brings this body back for A/B).
+// Ranks 33..CALS_RMAX (64) -- since the end of round 3 an A/B alternative only (CALS_HUGE_FROM=49|65 in the
+// environment): the update of every rank above CALS_RFAST is the pipeline of huge_* launches below (CALS_HUGE_FROM_DEFAULT).
 // Too wide for the register-resident bodies above; H / L (64 columns, ld 66: the
 // transposed-copy stores of a wave spread over 16 banks instead of one) live in dynamic LDS and the rows are solved
 // through the factor panel itself, one row per thread, SIXTEEN COLUMNS AT A TIME in registers:
@@ -1413,7 +1412,7 @@ __global__ void __launch_bounds__(UPD_THREADS, 1) update_huge_kernel(const Updat
   const int slot = a.slots[blockIdx.x];
   const int r = a.mt.rank[slot];
   const int huge_from = a.huge_from ? a.huge_from : CALS_RMAX + 1;
-  if (r <= CALS_RFAST || r > CALS_RMAX || (r >= huge_from && !a.rowdot)) return;  // the huge_* launches' models (update_launch)
+  if (r <= CALS_RFAST || r > CALS_RMAX || r >= huge_from) return;  // the huge_* launches' models (update_launch)
   update_body_huge<T>(a_ptr, slot, r, sh);
 }
 #undef UPD_DISPATCH

@@ -1314,9 +1314,12 @@ hipError_t nnls_launch(const NnlsArgs &a_in, hipStream_t st) {
     int waves = 4;
     while (waves > 1 && nnls_lds_bytes(a.rmax, waves) > budget) --waves;
     const size_t dyn = nnls_lds_bytes(a.rmax, waves);
-    // rows per workgroup: at least 4 per wave, enough workgroups to fill 256 CUs several times over
+    // rows per workgroup: enough workgroups to fill 256 CUs several times over; at least 4 rows per wave -- ONE for
+    // ranks 33..64, whose rows are long (a 64 x 64 factorisation per exchange) and whose models are few: one model of
+    // rank 64 next to C3's small ones cost +2.3 ms per sweep with 19 workgroups, its 300 rows four to a wave in turn
+    const int min_rows = (a.rhi > 32) ? 1 : 4;
     a.n_cls = n_models;
-    a.chunks = std::max(1, std::min((a.I + 4 * waves - 1) / (4 * waves), (4096 + n_models - 1) / n_models));
+    a.chunks = std::max(1, std::min((a.I + min_rows * waves - 1) / (min_rows * waves), (4096 + n_models - 1) / n_models));
     if (forced_chunks > 0) a.chunks = std::min(forced_chunks, a.I);
     const dim3 grid((unsigned)(n_models * a.chunks)), block(64 * waves);
     if (di)
