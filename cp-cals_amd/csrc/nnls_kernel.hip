@@ -619,6 +619,24 @@ __device__ __forceinline__ void nnls2_body(const NnlsArgs &a, int blk, int rmax_
     gs.xs = gs.cv + GS;
     gs.idx = reinterpret_cast<int *>(gs.xs + GS);
   }
+  T *fac = static_cast<T *>(a.factor) + (long long)I * col;
+  unsigned long long *actp = a.act + (long long)I * col;
+  double *rowdot = a.rowdot + (long long)I * k_model;
+  const int rows_per = (I + chunks_c - 1) / chunks_c;
+  const int row0 = chunk * rows_per, row1 = min(I, row0 + rows_per);
+  // the row's g and its stored active set are loaded ONE ROW AHEAD (the first one here, in front of the workgroup's
+  // set-up): the round trip runs under the previous row's solves instead of in front of this row's first one
+#ifdef CALS_NNLS2_SINGLE
+  const int row_first = row0 + wave, row_step = W;
+#else
+  const int row_first = row0 + NG * wave + g, row_step = NG * W;
+#endif
+  double y_next = 0.0;
+  unsigned long long act_next = 0;
+  if (row_first < row1) {
+    y_next = (l < r) ? (double)fac[row_first + (long long)I * l] : 0.0;
+    act_next = actp[row_first];
+  }
   for (int e = tid; e < r * r; e += blockDim.x) {
     const int i = e % r, j = e / r;
     double h = 1.0;
@@ -650,11 +668,6 @@ __device__ __forceinline__ void nnls2_body(const NnlsArgs &a, int blk, int rmax_
     __syncthreads();
     if (s_full_ok2) gs.fmask = rmask;
   }
-  T *fac = static_cast<T *>(a.factor) + (long long)I * col;
-  unsigned long long *actp = a.act + (long long)I * col;
-  double *rowdot = a.rowdot + (long long)I * k_model;
-  const int rows_per = (I + chunks_c - 1) / chunks_c;
-  const int row0 = chunk * rows_per, row1 = min(I, row0 + rows_per);
   int status = 0;
 
 #ifdef CALS_NNLS2_SINGLE  // debugging: group 0 alone, one row per wave
@@ -667,8 +680,12 @@ __device__ __forceinline__ void nnls2_body(const NnlsArgs &a, int blk, int rmax_
     if (row < row1) {  // (a chunk's tail leaves the last groups idle)
 #endif
       const bool in = l < r;
-      const double y = in ? (double)fac[row + (long long)I * l] : 0.0;
-      unsigned act = (unsigned)actp[row] & rmask;
+      const double y = y_next;
+      unsigned act = (unsigned)act_next & rmask;
+      if (row + row_step < row1) {
+        y_next = in ? (double)fac[row + row_step + (long long)I * l] : 0.0;
+        act_next = actp[row + row_step];
+      }
       act &= ~gballot<GS>(in && y > 0.0, g);
       double d = 0.0, sp = 0.0;
       int budget = NNLS_MAX_EXCHANGES(r);
