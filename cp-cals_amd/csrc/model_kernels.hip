@@ -1640,12 +1640,13 @@ __global__ void __launch_bounds__(HUGE_POTRF_THREADS) huge_potrf_kernel(const Up
     __builtin_amdgcn_wave_barrier();                          \
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");    \
   } while (0)
-#define HUGE_SOLVE_LDS_DOUBLES(rp) (16 * ((rp) + 4) + CALS_GLD + 2 * 16 * CALS_GLD)
+#define HUGE_SOLVE_LDS_DOUBLES(rp) (16 * ((rp) + 4) + CALS_GLD + 2 * 16 * (rp))  // slab, dinv, two panels of <= rp rows of L
 template <typename T>
 __global__ void __launch_bounds__(64) huge_solve_kernel(const UpdateArgs a_by_value) {
   (void)a_by_value;
   HUGE_PROLOGUE();
-  constexpr int LD = CALS_GLD, PANEL = 16 * CALS_GLD;
+  constexpr int LD = CALS_GLD;
+  const int PANEL = 16 * rp;  // a block's panel has at most rp rows of L (the launch sizes the LDS for the largest rp in flight)
   const double *__restrict__ H = a.hscratch + (long long)h * CALS_GLD * CALS_GLD;
   const int g = lane >> 4, n = lane & 15;
   const int row0 = blockIdx.x * 16;

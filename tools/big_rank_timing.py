@@ -1,6 +1,7 @@
 """How slow are the rank > 64 bodies (built to be right, not fast)?  Sweep time of C3's tensor shape with one
 model of rank r next to 255 models of ranks 1..20, against the 256 small models alone; both update methods.
-Usage: python tools/big_rank_timing.py [sweeps]"""
+Usage: python tools/big_rank_timing.py [sweeps [ranks...]]   (BIG_COUNT=n in the environment: n models of that rank instead of one)"""
+import os
 import sys
 import time
 
@@ -38,8 +39,9 @@ def main():
         t0 = run(modes, small + [20], X, um, sweeps)
         print("%-13s 256 models of ranks 1..20: %.2f ms per sweep" % (name, t0), flush=True)
         for r in [int(v) for v in sys.argv[2:]] or (65, 100, 128, 256):
-            t = run(modes, small + [r], X, um, sweeps)
-            print("%-13s 255 small + one rank-%-3d model: %.2f ms per sweep (+%.2f ms)" % (name, r, t, t - t0), flush=True)
+            nb = int(os.environ.get("BIG_COUNT", "1"))
+            t = run(modes, small + [r] * nb, X, um, sweeps)
+            print("%-13s 255 small + %d rank-%-3d model(s): %.2f ms per sweep (+%.2f ms)" % (name, nb, r, t, t - t0), flush=True)
 
 
 if __name__ == "__main__":
