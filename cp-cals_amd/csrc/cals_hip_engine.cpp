@@ -156,7 +156,7 @@ struct cals_hip_engine {
   int out_wpe = 2;
   void *partial = nullptr;
   size_t partial_elems = 0;
-  double *hscratch = nullptr;  // models of rank > CALS_RMAX: H / L blocks of the huge_* update launches
+  double *hscratch = nullptr;  // models of rank > CALS_RFAST: H / L blocks of the huge_* update launches (and of the EC line search above CALS_RMAX)
   size_t hscratch_blocks = 0;
   double *hrowdot = nullptr;   // ... and their rows' <z, z> (unconstrained update), [n_huge][I]
   size_t hrowdot_len = 0;
@@ -852,7 +852,7 @@ int sweep_once(cals_hip_engine *e, bool evict_enabled, bool defer_changed = fals
     prof_end(e, pk);
   }
   int rank_max = 1;  // sizes the update kernel's LDS panel
-  size_t n_huge = 0;  // models above CALS_RMAX: the update needs a global H / L block each
+  size_t n_huge = 0;  // models above CALS_RMAX: nnls_huge_kernel / the EC line search need global H / L blocks for them
   unsigned rank_classes = 0;  // which LDS size classes of the NNLS kernel are in flight
   int upd_classes = 0;        // update kernels to launch: bit 0 = ranks <= CALS_RFAST, bit 1 = 33..CALS_RMAX, bit 2 = above
   // The unconstrained update of the larger ranks is a pipeline of multi-workgroup launches (update_launch): from rank

@@ -177,9 +177,10 @@ struct UpdateArgs {
   // on their way out -- no pack_pt launch in front of that TTM.
   void *pt;
   int ptAp;
-  // Models above CALS_RMAX (ranks 65..CALS_GLD): their registry positions (n_huge of them; the engine's class list),
-  // the H / L block of model h is block h of hscratch.  Their update is a pipeline of launches (update_launch).
-  // hrowdot: [n_huge][I], written by the solve launch when rowdot is nullptr (unconstrained update).
+  // Models of rank >= huge_from (33 by default: every rank the register-resident bodies do not take): their registry
+  // positions (n_huge of them; a suffix of the engine's class list), the H / L block of model h is block h of hscratch.
+  // Their update is a pipeline of launches (update_launch).  hrowdot: [n_huge][I], written by the solve launch when
+  // rowdot is nullptr (unconstrained update).
   const int *huge_idx;
   int n_huge;
   int huge_from;       // smallest rank the pipeline takes (33 | 49 | CALS_RMAX + 1; 0 = CALS_RMAX + 1)
