@@ -81,7 +81,7 @@ EXPORTS = [
     "cals_hip_reset_kernel_stats", "cals_hip_stream", "cals_hip_device_count",
     "cals_hip_create_ex", "cals_hip_dtype", "cals_hip_tree", "cals_hip_set_tensor_f32",
     "cals_hip_rebind", "cals_hip_capacity", "cals_hip_set_sweep_log", "cals_hip_get_sweep_log",
-    "cals_hip_debug_clock", "cals_hip_debug_ttm_trace", "cals_hip_host_first_fit", "cals_hip_host_compress_plan", "cals_hip_host_active_cols",
+    "cals_hip_debug_clock", "cals_hip_debug_ttm_trace", "cals_hip_debug_install_crash_trace", "cals_hip_host_first_fit", "cals_hip_host_compress_plan", "cals_hip_host_active_cols",
 ]
 
 _LIB = None

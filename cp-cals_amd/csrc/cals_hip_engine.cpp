@@ -9,6 +9,11 @@
 #include "../../include/cals_hip.h"
 #include "cals_hip_internal.h"
 
+#include <execinfo.h>
+#include <signal.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -169,6 +174,15 @@ struct cals_hip_engine {
   size_t krp_elems = 0;
   unsigned long long *dbg_clock = nullptr;  // CALS_MTTKRP_CLOCK=1: in-kernel clock stamps
   unsigned long long *dbg_trace = nullptr;  // CALS_TTM_TRACE=1 (CALS_DIAG builds): ttm_kernel stage stamps
+
+  // CALS_HIP_VERIFY=1 (debugging): recompute-and-compare checks of every operand kept across launches (verify_*)
+  struct {
+    bool on = false;
+    void *pt2 = nullptr, *t2 = nullptr;
+    double *gram2[CALS_HIP_MAX_MODES] = {nullptr};
+    int *d_count = nullptr;
+    int64_t checks = 0;
+  } vfy;
 
   ModelTable mt{};
   int max_slots = 0;
@@ -672,20 +686,39 @@ Geo tree_geometry(const cals_hip_engine *e, int first, int64_t R) {
   return g;
 }
 
-int launch_ttm(cals_hip_engine *e, int first, int64_t R, Geo *geo_out) {
+int ensure_col_scratch(cals_hip_engine *e, size_t words, size_t n_idx);
+int arena_alloc(cals_hip_engine *e, size_t bytes, void **out);
+
+// ---- CALS_HIP_VERIFY=1 ----
+// Result of the comparison kernels launched since the last call: a difference is an engine error naming the operand.
+int verify_result(cals_hip_engine *e, const char *what, int mode) {
+  int bad = 0;
+  HIPCHK(hipMemcpyAsync(&bad, e->vfy.d_count, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  e->vfy.checks++;
+  if (bad) {
+    HIPCHK(hipMemsetAsync(e->vfy.d_count, 0, sizeof(int), e->stream));
+    return fail(e, CALS_HIP_ERR_STATE,
+                std::string("CALS_HIP_VERIFY: ") + what + " differs from its recomputation in " + std::to_string(bad) +
+                    " elements (sweep " + std::to_string(e->sweeps) + ", mode " + std::to_string(mode) + ")");
+  }
+  return CALS_HIP_OK;
+}
+VerifyArgs verify_args(cals_hip_engine *e) {
+  VerifyArgs v{};
+  v.slots = e->d_slots;
+  v.n_slots = (int)e->registry.size();
+  v.mt = e->mt;
+  v.dtype = e->dtype;
+  v.count = e->vfy.d_count;
+  return v;
+}
+
+TtmArgs ttm_args(cals_hip_engine *e, int first, int64_t R, const Geo &g) {
   TreePlan &tp = e->tree;
   const PairCfg &pc = tp.pair[first];
-  const int second = (first + 1) % 3, am = (first + 2) % 3;
+  const int second = (first + 1) % 3;
   const ModeLayout &L = e->lay[first];
-  const Geo g = tree_geometry(e, first, R);
-  if (tp.pt_mode != am || tp.pt_Ap != L.Ap) {  // not left behind by mode am's update launch (sweep_once)
-    const int pk = prof_begin(e, 2, 0, LOG_TTM);
-    HIPCHK(pack_pt_launch(e->factor[am], e->modes[am], L.A, L.Ap, g.NB, (int)R, tp.Pt, e->dtype,
-                          e->stream));
-    prof_end(e, pk);
-    tp.pt_mode = am;
-    tp.pt_Ap = L.Ap;
-  }
   TtmArgs a{};
   a.Xp = L.Xp;
   a.Pt = tp.Pt;
@@ -709,6 +742,103 @@ int launch_ttm(cals_hip_engine *e, int first, int64_t R, Geo *geo_out) {
   a.MT = pc.MT;
   a.dbg = getenv("CALS_TTM_DBG") ? atoi(getenv("CALS_TTM_DBG")) : 0;
   a.dbg_trace = e->dbg_trace;
+  return a;
+}
+
+// The T that waits for mode t_second must be the TTM of the CURRENT factor of the pair's inner mode: recompute it
+// (fresh pack, fresh TTM into a second buffer; the partial tiles it also writes are free at this point) and compare
+// the in-flight models' columns -- all but those a NO_ERROR_CHECKING line search rewrote, which are patched.
+int verify_pending_t(cals_hip_engine *e, int64_t R) {
+  TreePlan &tp = e->tree;
+  const int first = tp.t_first, am = (first + 2) % 3;
+  const ModeLayout &L = e->lay[first];
+  const Geo g = tree_geometry(e, first, R);
+  HIPCHK(pack_pt_launch(e->factor[am], e->modes[am], L.A, L.Ap, g.NB, (int)R, e->vfy.pt2, e->dtype, e->stream));
+  TtmArgs a = ttm_args(e, first, R, g);
+  a.Pt = e->vfy.pt2;
+  a.Tout = e->vfy.t2;
+  HIPCHK(ttm_launch(a, e->stream));
+  VerifyArgs v = verify_args(e);
+  v.a = tp.Tbuf;
+  v.b = e->vfy.t2;
+  v.kind = 0;
+  v.rows = L.S * (long long)L.Mp;
+  v.skip_flagged = tp.n_stale > 0 ? 1 : 0;
+  HIPCHK(verify_launch(v, e->stream));
+  return verify_result(e, "the pending T", tp.t_second);
+}
+
+// Gramians of the modes other than n (what hadamard_but_one is about to read) against A^T A of the current factors
+int verify_gramians(cals_hip_engine *e, int n) {
+  GramInitArgs g{};
+  g.slots = e->d_slots;
+  g.n_slots = (int)e->registry.size();
+  g.mt = e->mt;
+  for (int m = 0; m < e->n_modes; m++) {
+    g.factor[m] = e->factor[m];
+    g.I[m] = (int)e->modes[m];
+    g.gram[m] = e->vfy.gram2[m];
+  }
+  g.n_modes = e->n_modes;
+  g.dtype = e->dtype;
+  HIPCHK(gram_init_launch(g, e->stream));
+  for (int m = 0; m < e->n_modes; m++) {
+    if (m == n) continue;
+    VerifyArgs v = verify_args(e);
+    v.a = e->gram[m];
+    v.b = e->vfy.gram2[m];
+    v.kind = 3;
+    v.tol = 1e-11;
+    HIPCHK(verify_launch(v, e->stream));
+  }
+  return verify_result(e, "a Gramian of another mode", n);
+}
+
+// "free columns inside the active width are zero" (multi_ktensor.cpp:148-150: remove zeroes them; the MTTKRP kernels
+// run over them).  Beyond the active width a compress leaves stale copies of the models it moved, here as in the
+// reference (Ktensor::attach copies, nothing clears the source, multi_ktensor.cpp:222-229): no kernel reads there,
+// and an admission overwrites every row of the columns it takes.
+int verify_free_columns(cals_hip_engine *e) {
+  std::vector<int> free_cols;
+  for (int64_t c = 0; c < e->end; c++)
+    if (e->occ[(size_t)c] == 0) free_cols.push_back((int)c);
+  if (free_cols.empty()) return CALS_HIP_OK;
+  int rc = ensure_col_scratch(e, 0, free_cols.size());
+  if (rc) return rc;
+  int *h = nullptr;
+  if ((rc = arena_alloc(e, free_cols.size() * sizeof(int), (void **)&h))) return rc;
+  std::memcpy(h, free_cols.data(), free_cols.size() * sizeof(int));
+  HIPCHK(hipMemcpyAsync(e->d_colidx, h, free_cols.size() * sizeof(int), hipMemcpyHostToDevice, e->stream));
+  for (int m = 0; m < e->n_modes; m++)
+    HIPCHK(verify_zero_launch(e->factor[m], e->modes[m], e->dtype, e->d_colidx, (int)free_cols.size(),
+                              e->vfy.d_count, e->stream));
+  return verify_result(e, "a free column of a multi-factor (must be zero)", -1);
+}
+
+int launch_ttm(cals_hip_engine *e, int first, int64_t R, Geo *geo_out) {
+  TreePlan &tp = e->tree;
+  const int second = (first + 1) % 3, am = (first + 2) % 3;
+  const ModeLayout &L = e->lay[first];
+  const Geo g = tree_geometry(e, first, R);
+  if (tp.pt_mode != am || tp.pt_Ap != L.Ap) {  // not left behind by mode am's update launch (sweep_once)
+    const int pk = prof_begin(e, 2, 0, LOG_TTM);
+    HIPCHK(pack_pt_launch(e->factor[am], e->modes[am], L.A, L.Ap, g.NB, (int)R, tp.Pt, e->dtype,
+                          e->stream));
+    prof_end(e, pk);
+    tp.pt_mode = am;
+    tp.pt_Ap = L.Ap;
+  } else if (e->vfy.on) {  // the bookkeeping says Pt mirrors factor am: pack it again and compare
+    HIPCHK(pack_pt_launch(e->factor[am], e->modes[am], L.A, L.Ap, g.NB, (int)R, e->vfy.pt2, e->dtype, e->stream));
+    VerifyArgs v = verify_args(e);
+    v.a = tp.Pt;
+    v.b = e->vfy.pt2;
+    v.kind = 1;
+    v.rows = L.Ap;
+    HIPCHK(verify_launch(v, e->stream));
+    int rc = verify_result(e, "the packed operand Pt left by the update launch", first);
+    if (rc) return rc;
+  }
+  const TtmArgs a = ttm_args(e, first, R, g);
   if ((size_t)g.NB * g.T * (size_t)L.ldPart * CALS_BN > e->partial_elems)
     return fail(e, CALS_HIP_ERR_STATE, "internal: partial buffer too small");
   double total = 1.0;
@@ -915,6 +1045,7 @@ int sweep_once(cals_hip_engine *e, bool evict_enabled, bool defer_changed = fals
   // without a line search nothing runs between the last mode's update and the end-of-sweep rule: the update
   // launch applies it (UpdateArgs::fin) and finish_kernel is not launched
   const bool fin_in_update = !e->prm.line_search && (!e->prm.always_evict_first || !evict_enabled);
+  if (e->vfy.on && (rc = verify_free_columns(e))) return rc;
   for (int n = 0; n < e->n_modes; n++) {
     e->cur_mode = n;
     Geo g{0, 0};
@@ -956,6 +1087,7 @@ int sweep_once(cals_hip_engine *e, bool evict_enabled, bool defer_changed = fals
     }
     const bool by_contract = e->tree.on && e->tree.t_second == n;
     if (by_contract) {
+      if (e->vfy.on && (rc = verify_pending_t(e, R))) return rc;
       if ((rc = launch_contract(e, R, e->factor[n]))) return rc;
       if (e->tree.n_stale > 0 && (rc = patch_stale_columns(e, n))) return rc;
       tree_invalidate(e);  // T is consumed: mode a of the pair is updated next
@@ -987,6 +1119,7 @@ int sweep_once(cals_hip_engine *e, bool evict_enabled, bool defer_changed = fals
       HIPCHK(hipStreamWaitEvent(e->stream, e->ev_join, 0));
       u.huge_factored = 1;
     }
+    if (e->vfy.on && (rc = verify_gramians(e, n))) return rc;
     const int pk = prof_begin(e, 1, 0, LOG_UPDATE);
     // The update bodies for ranks <= CALS_RFAST sum the split-K partial tiles of their model's columns themselves
     // (UpdateArgs::partial): no reduce launch, no round trip of G through the factor buffer.  The NNLS kernel and
@@ -1787,6 +1920,23 @@ int cals_hip_create_ex(cals_hip_engine **out, int n_modes, const int64_t *modes,
   }
   (void)part_rows_max;
   if ((rc = dev_alloc_elems(e, &e->partial, e->partial_elems))) return rc;
+  if (getenv("CALS_HIP_VERIFY")) {  // debugging: second copies of Pt, T and the Gramian stores for the verify_* checks
+    e->vfy.on = true;
+    if ((rc = dev_alloc(e, &e->vfy.d_count, (size_t)1))) return rc;
+    for (int n = 0; n < n_modes; n++)
+      if ((rc = dev_alloc(e, &e->vfy.gram2[n], (size_t)(CALS_GLD * buffer_size)))) return rc;
+    if (e->tree.on) {
+      size_t t_elems = 0, pt_elems = 0;
+      for (int n = 0; n < 3; n++) {
+        if (!e->tree.pair[n].on) continue;
+        const ModeLayout &L = e->lay[n];
+        t_elems = std::max(t_elems, nb_max * CALS_BN * (size_t)L.S * (size_t)L.Mp);
+        pt_elems = std::max(pt_elems, nb_max * (size_t)L.Ap * CALS_BN);
+      }
+      if ((rc = dev_alloc_elems(e, &e->vfy.pt2, pt_elems))) return rc;
+      if ((rc = dev_alloc_elems(e, &e->vfy.t2, t_elems))) return rc;
+    }
+  }
   if (krp_max) {
     e->krp_elems = krp_max;
     if ((rc = dev_alloc_elems(e, &e->krp_ws, krp_max))) return rc;
@@ -1937,6 +2087,10 @@ int cals_hip_destroy(cals_hip_engine *e) {
   }
   fr(e->nnls_hscratch);
   fr(e->d_hcounter);
+  fr(e->vfy.pt2);
+  fr(e->vfy.t2);
+  fr(e->vfy.d_count);
+  for (int n = 0; n < CALS_HIP_MAX_MODES; n++) fr(e->vfy.gram2[n]);
   fr(e->tree.Tbuf);
   fr(e->tree.Pt);
   fr(e->tree.d_changed);
@@ -2620,6 +2774,64 @@ int64_t cals_hip_host_compress_plan(const int64_t *occupancy, int64_t n_cols, in
 int64_t cals_hip_host_active_cols(const int64_t *occupancy, int64_t n_cols) {
   if (!occupancy || n_cols < 1) return 0;
   return active_cols_of(occupancy, n_cols);
+}
+
+// ---- fatal-signal evidence (tests/conftest.py) ----
+// A GPU memory fault ends in abort() on one of the runtime's threads, after ONE line on stderr ("Memory access fault
+// by GPU ... on address ...").  Under a test runner that captures file descriptor 2 into a temporary file, that line
+// dies with the process and only the runner's own "Fatal Python error: Aborted" survives (round 3: an abort nobody
+// could attribute until the same build's bench logs showed the fault line).  The handler installed here writes, to a
+// descriptor the caller saved BEFORE the capture started: what the current stderr file holds (the captured output of
+// the running test, if fd 2 is a regular file other than the evidence file), then a backtrace of the faulting
+// thread; then it hands the signal to whoever was installed before (the runner's own fault handler) and finally to
+// the default action.  Only async-signal-safe calls.
+namespace {
+int g_evidence_fd = -1;
+struct sigaction g_prev_action[65];
+void on_fatal_signal(int sig) {
+  const int out = g_evidence_fd;
+  auto put = [&](const char *t) { ssize_t w = write(out, t, strlen(t)); (void)w; };
+  put("\n*** cals_hip crash trace: signal ");
+  put(sig == SIGSEGV ? "SIGSEGV" : sig == SIGBUS ? "SIGBUS" : sig == SIGABRT ? "SIGABRT" : sig == SIGFPE ? "SIGFPE" : "SIGILL");
+  struct stat s2, so;
+  if (fstat(2, &s2) == 0 && fstat(out, &so) == 0 && S_ISREG(s2.st_mode) &&
+      !(s2.st_dev == so.st_dev && s2.st_ino == so.st_ino)) {
+    put("; captured stderr of the running test:\n");
+    char buf[4096];
+    off_t at = 0;
+    while (at < s2.st_size) {
+      const ssize_t n = pread(2, buf, sizeof(buf), at);
+      if (n <= 0) break;
+      ssize_t w = write(out, buf, (size_t)n);
+      (void)w;
+      at += n;
+    }
+  }
+  put("\n*** backtrace of the faulting thread:\n");
+  void *frames[96];
+  const int n = backtrace(frames, 96);
+  backtrace_symbols_fd(frames, n, out);
+  sigaction(sig, &g_prev_action[sig], nullptr);  // the previous handler (or the default action) takes over
+  raise(sig);
+}
+}  // namespace
+
+int cals_hip_debug_install_crash_trace(int evidence_fd) {
+  if (evidence_fd < 0) return CALS_HIP_ERR_ARG;
+  void *warm[2];
+  (void)backtrace(warm, 2);  // loads the unwinder now, not inside the handler
+  const bool installed = g_evidence_fd >= 0;
+  g_evidence_fd = evidence_fd;
+  if (installed) return CALS_HIP_OK;  // a second call only moves the evidence descriptor
+  for (int sig : {SIGSEGV, SIGBUS, SIGABRT, SIGFPE, SIGILL}) {
+    struct sigaction sa;
+    memset(&sa, 0, sizeof(sa));
+    sa.sa_handler = on_fatal_signal;
+    sigemptyset(&sa.sa_mask);
+    sa.sa_flags = SA_NODEFER;
+    if (sigaction(sig, &sa, &g_prev_action[sig]) != 0) return CALS_HIP_ERR_STATE;
+  }
+  return CALS_HIP_OK;
 }
 
 }  // extern "C"

@@ -362,5 +362,23 @@ hipError_t gather_columns_launch(const ColMoveArgs &a, hipStream_t st);
 hipError_t scatter_columns_launch(const ColMoveArgs &a, hipStream_t st);
 hipError_t set_cols_launch(const int *pairs, int n, int *col, hipStream_t st);
 
+// CALS_HIP_VERIFY=1 (debugging): compare two buffers over the elements the in-flight models own (model_kernels.hip)
+struct VerifyArgs {
+  const int *slots;
+  int n_slots;
+  ModelTable mt;
+  const void *a, *b;   // the kept operand and its recomputation, same layout
+  int kind;            // 0: column major, `rows` elements per column (factor-like; T: rows = S * Mp);
+                       // 1: Pt[(column block)][rows][CALS_BN]; 3: Gramian store (CALS_GLD x buffer, doubles, |a - b| <= tol)
+  long long rows;
+  int dtype;           // element type of kinds 0 / 1
+  int skip_flagged;    // skip the models the last line-search launch rewrote (mt.flags & 3): their columns are patched
+  double tol;
+  int *count;          // += number of differing elements
+};
+hipError_t verify_launch(const VerifyArgs &a, hipStream_t st);
+hipError_t verify_zero_launch(const void *buf, long long rows, int dtype, const int *cols, int n, int *count,
+                              hipStream_t st);
+
 }  // namespace calship
 #endif

@@ -2874,4 +2874,70 @@ hipError_t set_cols_launch(const int *pairs, int n, int *col, hipStream_t st) {
   return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------
+// CALS_HIP_VERIFY=1 (debugging switch of the engine): recompute-and-compare checks of everything the engine
+// keeps ACROSS launches -- the packed operand Pt an update launch leaves behind, a T that waits for its second
+// mode (also over the sweep boundary), the Gramians of the other modes, the all-zero free columns.  A stale
+// operand is a wrong result of the size of one sweep's progress, which a converging model hides within the
+// test tolerances more often than not; these kernels make it an error at the launch that would consume it.
+// One workgroup per in-flight model (x a slice of its elements); `count` gets the number of differing elements.
+// ---------------------------------------------------------------------------------------------
+template <typename E>
+__global__ void __launch_bounds__(256) verify_kernel(const VerifyArgs a) {
+  const int slot = a.slots[blockIdx.x];
+  if (a.skip_flagged && (a.mt.flags[slot] & 3)) return;
+  const int col = a.mt.col[slot], r = a.mt.rank[slot];
+  const E *A = static_cast<const E *>(a.a), *B = static_cast<const E *>(a.b);
+  int bad = 0;
+  if (a.kind == 3) {  // r x r Gramian block, ld CALS_GLD, relative tolerance (different summation orders)
+    for (int e = threadIdx.x; e < r * r; e += 256) {
+      const long long at = (e % r) + (long long)CALS_GLD * (col + e / r);
+      const double x = (double)A[at], y = (double)B[at];
+      if (x != x && y != y) continue;  // a diverged model: NaN on both sides
+      if (!(fabs(x - y) <= a.tol * fmax(1.0, fmax(fabs(x), fabs(y))))) bad++;
+    }
+  } else if (a.kind == 1) {  // Pt[(column block)][row < rows][128]
+    for (long long e = threadIdx.x; e < a.rows * r; e += 256) {
+      const int gc = col + (int)(e % r);
+      const long long at = ((long long)(gc >> 7) * a.rows + e / r) * CALS_BN + (gc & (CALS_BN - 1));
+      if (A[at] != B[at] && !(A[at] != A[at] && B[at] != B[at])) bad++;
+    }
+  } else {  // column major, `rows` elements per column
+    for (long long e = threadIdx.x; e < a.rows * r; e += 256) {
+      const long long at = a.rows * col + e;
+      if (A[at] != B[at] && !(A[at] != A[at] && B[at] != B[at])) bad++;
+    }
+  }
+  if (bad) atomicAdd(a.count, bad);
+}
+
+hipError_t verify_launch(const VerifyArgs &a, hipStream_t st) {
+  if (a.n_slots <= 0) return hipSuccess;
+  if (a.kind == 3 || a.dtype != CALS_F32)
+    hipLaunchKernelGGL(verify_kernel<double>, dim3(a.n_slots), dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL(verify_kernel<float>, dim3(a.n_slots), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+
+// the columns listed in `cols` (free columns of the multi-factor) must hold zeros in all `rows` rows
+template <typename E>
+__global__ void __launch_bounds__(256) verify_zero_kernel(const E *buf, long long rows, const int *cols, int *count) {
+  const E *p = buf + rows * cols[blockIdx.x];
+  int bad = 0;
+  for (long long i = threadIdx.x; i < rows; i += 256)
+    if (!(p[i] == (E)0)) bad++;
+  if (bad) atomicAdd(count, bad);
+}
+
+hipError_t verify_zero_launch(const void *buf, long long rows, int dtype, const int *cols, int n, int *count,
+                              hipStream_t st) {
+  if (n <= 0) return hipSuccess;
+  if (dtype == CALS_F32)
+    hipLaunchKernelGGL(verify_zero_kernel<float>, dim3(n), dim3(256), 0, st, (const float *)buf, rows, cols, count);
+  else
+    hipLaunchKernelGGL(verify_zero_kernel<double>, dim3(n), dim3(256), 0, st, (const double *)buf, rows, cols, count);
+  return hipGetLastError();
+}
+
 }  // namespace calship

@@ -283,6 +283,13 @@ int cals_hip_debug_clock(cals_hip_engine *e, int n_workgroups, double *cycles_me
  * before the DMA wait / before / after the stage barrier by waves 0 and 4 of 8 workgroups of the
  * last ttm_kernel launch: out[((wg * 2 + group) * 512 + stage) * 4 + {0, 1, 2}] (tools/ttm_trace.py) */
 int cals_hip_debug_ttm_trace(cals_hip_engine *e, uint64_t *out, int n);
+/* Fatal-signal evidence for host processes that capture file descriptor 2 (test runners): on SIGSEGV / SIGBUS /
+ * SIGABRT / SIGFPE / SIGILL the contents of the current stderr file (if it is a regular file other than
+ * evidence_fd: the capture of the running test, with the runtime's "Memory access fault by GPU" line in it) and a
+ * backtrace of the faulting thread are written to evidence_fd -- a descriptor the caller saved before the capture
+ * began --, then the previously installed handler and the default action run.  Replaces nothing in the reference
+ * (its fatal device errors print to cerr and exit(EXIT_FAILURE), src/cuda_utils.cpp:28-90). */
+int cals_hip_debug_install_crash_trace(int evidence_fd);
 /* number of HIP devices visible (0 when none); never initialises a context on failure */
 int cals_hip_device_count(void);
 

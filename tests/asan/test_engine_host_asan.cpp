@@ -9,13 +9,18 @@
 // or an offset as a sanitizer report.
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <fstream>
 #include <random>
+#include <sstream>
+#include <string>
 #include <vector>
 
 #include "als.h"
 #include "cals.h"
 #include "../../include/cals_hip.h"
+#include "fake_device.h"
 
 static int failures = 0;
 #define CHECK(cond)                                                  \
@@ -267,12 +272,118 @@ static void cpp_layer_driver_pattern() {
   CHECK(cp_cals(X, queue, cp).n_ktensors == 12);
 }
 
-int main() {
-  c_abi_life_cycles(CALS_HIP_F64);
-  c_abi_life_cycles(CALS_HIP_F32);
-  stepwise_api();
-  n_way_group_tree();
-  cpp_layer_driver_pattern();
+// The call patterns of the two round-3 anomalies, replayed on the fake device with the eviction
+// schedule of the real run (tests/asan/patterns.txt, written by tools/make_asan_patterns.py from the oracle): the
+// model admitted k-th leaves at the iteration at which the real run evicted it, so admission, eviction, compress and
+// the pending-T bookkeeping take the very sequence of decisions they took on the GPU.  Every model must come back
+// bit-identical with exactly that iteration count; CALS_HIP_VERIFY is on (free columns are checked before every sweep).
+struct Pattern {
+  std::string name, plan, api;
+  std::vector<int64_t> modes;
+  int64_t buffer = 0, max_iter = 0;
+  int ls = 0, ls_method = 0, ls_interval = 0;
+  std::vector<int> ranks;
+  std::vector<long long> iters;
+};
+
+static std::vector<Pattern> read_patterns(const char *path) {
+  std::vector<Pattern> out;
+  std::ifstream in(path);
+  std::string word;
+  while (in >> word) {
+    if (word != "pattern") break;
+    Pattern p;
+    p.modes.resize(3);
+    size_t n = 0;
+    in >> p.name >> p.modes[0] >> p.modes[1] >> p.modes[2] >> p.buffer >> p.max_iter >> p.ls >> p.ls_method >> p.ls_interval >>
+        p.plan >> p.api >> n;
+    p.ranks.resize(n);
+    p.iters.resize(n);
+    for (size_t k = 0; k < n; k++) in >> p.ranks[k] >> p.iters[k];
+    out.push_back(p);
+  }
+  return out;
+}
+
+static void replay_patterns(const char *path) {
+  const auto patterns = read_patterns(path);
+  CHECK(patterns.size() == 2);
+  setenv("CALS_HIP_VERIFY", "1", 1);
+  for (const auto &p : patterns) {
+    if (p.plan != "auto") setenv("CALS_HIP_TREE", p.plan.c_str(), 1);
+    auto models = make_models(p.modes, p.ranks, 4242);
+    cals_hip_engine *e = nullptr;
+    CHECK(cals_hip_create(&e, 3, p.modes.data(), p.buffer, 0) == CALS_HIP_OK);
+    CHECK(p.plan != "M" || cals_hip_tree(e) == 3);
+    std::vector<double> X((size_t)(p.modes[0] * p.modes[1] * p.modes[2]), 0.5);
+    CHECK(cals_hip_set_tensor(e, X.data()) == CALS_HIP_OK);
+    cals_hip_params prm;
+    cals_hip_default_params(&prm);
+    prm.max_iterations = p.max_iter;
+    prm.tol = 1e-5;
+    prm.line_search = p.ls;
+    prm.line_search_method = p.ls_method;
+    prm.line_search_interval = p.ls_interval;
+    CHECK(cals_hip_set_params(e, &prm) == CALS_HIP_OK);
+    fake_set_schedule(p.iters);
+    for (auto &m : models) {
+      std::vector<double *> ptr;
+      for (auto &v : m.f) ptr.push_back(v.data());
+      CHECK(cals_hip_enqueue(e, m.rank, ptr.data(), m.lam.data(), -1, 0, &m.ticket) == CALS_HIP_OK);
+    }
+    auto check_model = [&](size_t k, const cals_hip_model_status &st) {
+      CHECK(st.iters == p.iters[k]);
+      CHECK(models[k].f == models[k].f0 && models[k].lam == models[k].lam0);
+    };
+    if (p.api == "step") {  // tests/test_gpu_async_eviction.py: result() polled after every step
+      std::vector<char> done(models.size(), 0);
+      int guard = 0;
+      while ((cals_hip_queue_size(e) || cals_hip_models_in_flight(e)) && guard++ < 10000) {
+        const int rc = cals_hip_step(e, nullptr, nullptr);
+        if (rc != CALS_HIP_OK) std::printf("step: %s\n", cals_hip_last_error(e));
+        CHECK(rc == CALS_HIP_OK);
+        for (size_t k = 0; k < models.size(); k++) {
+          if (done[k]) continue;
+          cals_hip_model_status st;
+          CHECK(cals_hip_model_result(e, models[k].ticket, &st) == CALS_HIP_OK);
+          if (st.evicted) {  // whatever is reported as evicted must already be final
+            done[k] = 1;
+            check_model(k, st);
+          }
+        }
+      }
+      for (auto d : done) CHECK(d);
+    } else {
+      cals_hip_report rep;
+      const int rc = cals_hip_run(e, &rep);
+      if (rc != CALS_HIP_OK) std::printf("run: %s\n", cals_hip_last_error(e));
+      CHECK(rc == CALS_HIP_OK && rep.n_ktensors == (int64_t)models.size());
+      for (size_t k = 0; k < models.size(); k++) {
+        cals_hip_model_status st;
+        CHECK(cals_hip_model_result(e, models[k].ticket, &st) == CALS_HIP_OK && st.evicted);
+        check_model(k, st);
+      }
+    }
+    fake_set_schedule({});
+    CHECK(cals_hip_destroy(e) == CALS_HIP_OK);
+    unsetenv("CALS_HIP_TREE");
+  }
+  unsetenv("CALS_HIP_VERIFY");
+}
+
+int main(int argc, char **argv) {
+  const char *patterns = argc > 1 ? argv[1] : nullptr;
+  // twice: a device that completes everything at once, then one that is as late as the API allows (fake_device.cpp)
+  for (int deferred = 0; deferred < 2; deferred++) {
+    fake_set_deferred(deferred != 0);
+    c_abi_life_cycles(CALS_HIP_F64);
+    c_abi_life_cycles(CALS_HIP_F32);
+    stepwise_api();
+    n_way_group_tree();
+    cpp_layer_driver_pattern();
+    if (patterns) replay_patterns(patterns);
+  }
+  fake_set_deferred(false);
   std::printf(failures ? "engine host asan: %d FAILED\n" : "engine host asan: all checks passed\n", failures);
   return failures ? 1 : 0;
 }

@@ -126,16 +126,35 @@ def test_host_api_under_asan_ubsan(tmp_path):
 
 def test_engine_host_side_under_asan_ubsan_on_a_fake_device():
     """cals_hip_engine.cpp's host logic + the C++ layer, life cycles with queueing / eviction / compress /
-    rebind / two engines / the CLI driver's call pattern, under ASan + UBSan + LeakSanitizer on the fake
-    device of tests/asan/fake_device.cpp (numeric kernels are no-ops there, so every model must come back
-    bit-identical)."""
+    rebind / two engines / the CLI driver's call pattern, under ASan + UBSan + LeakSanitizer + libstdc++ assertions on
+    the fake device of tests/asan/fake_device.cpp (numeric kernels are no-ops there, so every model must come back
+    bit-identical) -- once with a device that completes every stream operation at once and once with one that is as
+    late as the API allows -- and the replay of the two round-3 anomalies' call patterns with the eviction schedule
+    of the real runs (tests/asan/patterns.txt, from the oracle: tools/make_asan_patterns.py), CALS_HIP_VERIFY on."""
     exe = os.path.join(ROOT, "tests", "asan", "test_engine_host_asan")
     assert os.path.exists(exe), "run __graft_entry__.build() first"
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
-    r = subprocess.run([exe], capture_output=True, text=True, timeout=900, env=env)
+    r = subprocess.run([exe, os.path.join(ROOT, "tests", "asan", "patterns.txt")], capture_output=True, text=True,
+                       timeout=900, env=env)
     print(r.stdout[-2000:], r.stderr[-6000:])
     assert r.returncode == 0 and "all checks passed" in r.stdout, r.stderr[-4000:]
     assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr and "LeakSanitizer" not in r.stderr
+
+
+def test_engine_host_side_under_thread_sanitizer():
+    """The same program under ThreadSanitizer: CalsParams::devices = {0, 0} runs two engines from two host threads
+    that claim models from one queue through a shared atomic counter (cals/cals.cpp: cp_cals_devices)."""
+    exe = os.path.join(ROOT, "tests", "asan", "test_engine_host_tsan")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=1:second_deadlock_stack=1")
+    # (ASLR off for the child: this kernel's 32-bit mmap entropy trips older TSan runtimes, "unexpected memory mapping")
+    cmd = [exe, os.path.join(ROOT, "tests", "asan", "patterns.txt")]
+    if os.path.exists("/usr/bin/setarch"):
+        cmd = ["/usr/bin/setarch", os.uname().machine, "-R"] + cmd
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1800, env=env)
+    print(r.stdout[-2000:], r.stderr[-6000:])
+    assert r.returncode == 0 and "all checks passed" in r.stdout, r.stderr[-4000:]
+    assert "WARNING: ThreadSanitizer" not in r.stderr
 
 
 ORACLE_UNDER_ASAN = r"""
