@@ -137,6 +137,12 @@ def self_launch(n):
     return subprocess.call(cmd, env=env)
 
 
+def device_used_gib(torch, dev):
+    """GiB of the device in use right now (everything: this process's engines, the runtime, other processes)."""
+    free_b, total_b = torch.cuda.mem_get_info(dev)
+    return round((total_b - free_b) / 2.0 ** 30, 3), round(total_b / 2.0 ** 30, 1)
+
+
 def strong_c5_leg(cc, inputs, sharding, torch, X, world, rank, local_rank, steps, warmup, red_dev):
     """BASELINE config 5 next to the weak line: 2048 jackknife models IN TOTAL on C3's X, model m -> GPU m mod N,
     one step = one sweep of the whole job, job rate = K / max-over-ranks time of its own barrier-bracketed region.
@@ -171,8 +177,10 @@ def strong_c5_leg(cc, inputs, sharding, torch, X, world, rank, local_rank, steps
     per_rank_ms = [round(t / steps * 1e3, 4) for t in sharding.gather_over_ranks(elapsed, device=red_dev)]
     ks = eng.kernel_stats()
     eng.set_profiling(False)
+    used_gib, _ = device_used_gib(torch, torch.device("cuda", local_rank))
     eng.close()
     out = {"metric": "ALS iterations/sec of the whole 2048-model job", "value": round(value, 3), "unit": "ALS it/s",
+           "device_memory_in_use_GiB": used_gib,
            "scaling": "strong", "n_gpus": world, "steps": steps, "warmup": warmup,
            "ms_per_step": round(t_max / steps * 1e3, 4), "ms_per_step_per_rank": per_rank_ms,
            "total_models": total, "models_on_rank0": len(mine), "columns_on_rank0": R, "jackknife": True,
@@ -205,6 +213,9 @@ def main():
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args.gpus))
+    # dmabuf IPC only on this pool: RCCL's hipIpcGetMemHandle fails without it.  Set here as well as in self_launch, so
+    # that a rank started by somebody else's launcher (the driver's torchrun) has it before the runtime initialises.
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
     import numpy as np  # noqa: F401
     import torch
@@ -302,6 +313,7 @@ def main():
     ks = eng.kernel_stats()
     plan = eng.tree
     eng.set_profiling(False)
+    used_gib, total_gib = device_used_gib(torch, dev)   # this leg's engine resident (X copies, factors, T, partials)
 
     # ---- beside the contract: the long-run rate and the loop users run (not part of `value`) ----
     steady = run_loop = None
@@ -386,6 +398,8 @@ def main():
                              dom, "f32_16x16x4_f32" if dtype == "f32" else "f64_16x16x4_f64"),
                          "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4), "traffic": traffic,
+                         "traffic_source": "stored PMC figure: profiles/traffic.json, from separate rocprofv3 --pmc passes "
+                                           "of this command (rocprofv3 cannot run inside this process); not measured in this run",
                          "flops_per_launch": flops_per_launch, "avg_launch_ms": round(avg_ms, 4),
                          "launches": kern[dom]["launches"],
                          "plan": {0: "3 fused MTTKRPs per sweep", 1: "dimension tree A (modes 0,1 share X x_2 C)",
@@ -399,6 +413,9 @@ def main():
             "run_loop": run_loop,
             "dist": {"backend": args.dist_backend if world > 1 else None, "world_size": pg_world,
                      "ms_per_step_per_rank": per_rank_ms},
+            # rank 0's device with this leg's engine resident; the strong leg (its own engine, created after this one
+            # is closed) reports its own figure under strong_c5: the two legs never hold device memory at the same time
+            "device_memory": {"in_use_GiB": used_gib, "total_GiB": total_gib},
         }
     eng.close()
     if args.workload == "c3" and not args.no_strong_leg:

@@ -92,10 +92,13 @@ def load_library():
     global _LIB
     if _LIB is not None:
         return _LIB
-    if not os.path.exists(LIB_PATH):
+    # CALS_HIP_LIB=<path>: an experiment build of the same library (tools/ab_libs.sh, tools/ttm_strip.sh) for THIS
+    # process only -- the shipped file is never overwritten
+    path = os.environ.get("CALS_HIP_LIB") or LIB_PATH
+    if not os.path.exists(path):
         raise CalsHipError(ERR_NO_DEVICE, "%s not built (run __graft_entry__.build()); the engine "
-                           "has no CPU fallback" % LIB_PATH)
-    lib = C.CDLL(LIB_PATH)
+                           "has no CPU fallback" % path)
+    lib = C.CDLL(path)
     vp, i64, dp = C.c_void_p, C.c_int64, C.POINTER(C.c_double)
     lib.cals_hip_create.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(i64), i64, C.c_int]
     lib.cals_hip_create_ex.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(i64), i64, C.c_int, C.c_int]

@@ -69,5 +69,35 @@ def build(force=False, verbose=False):
     return LIB
 
 
+def build_variant(name, defs, sources=None, verbose=False):
+    """An experiment build next to the product: build/variants/libcals_hip_<name>.so from the sources listed in
+    `sources` (default: all) compiled with the extra -D switches `defs`, the other objects taken from the
+    production build.  Selected per process with CALS_HIP_LIB=<path> (cp_cals_amd.load_library; tools/ab_libs.sh);
+    the shipped libcals_hip.so is not touched."""
+    build()
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    vdir = os.path.join(HERE, "build", "variants")
+    os.makedirs(os.path.join(vdir, name), exist_ok=True)
+    objs = []
+    for s in SOURCES:
+        prod = os.path.join(HERE, "build", os.path.splitext(s)[0] + ".o")
+        if sources is not None and s not in sources:
+            objs.append(prod)
+            continue
+        obj = os.path.join(vdir, name, os.path.splitext(s)[0] + ".o")
+        cmd = [hipcc] + FLAGS + list(defs) + ["-x", "hip", "-c", os.path.join(CSRC, s), "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+        objs.append(obj)
+    lib = os.path.join(vdir, "libcals_hip_%s.so" % name)
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs)
+    return lib
+
+
 if __name__ == "__main__":
-    print(build(verbose=True))
+    import sys
+    if len(sys.argv) >= 3 and sys.argv[1] == "variant":  # build.py variant <name> "<-D...>" [source ...]
+        print(build_variant(sys.argv[2], sys.argv[3].split() if len(sys.argv) > 3 else [], sys.argv[4:] or None, verbose=True))
+    else:
+        print(build(verbose=True))

@@ -72,13 +72,21 @@ struct TtmCfg {
   static constexpr int QOFF = SLAB;                  // the stage's 128 Q values
   static constexpr int QPE = 256 / ES;               // Q elements per 4-byte-per-lane DMA piece
   static constexpr int QPIECES = CALS_BN / QPE;      // 4 (f64) or 2 (f32)
-  static constexpr int POFF = SLAB + CALS_BN;        // P tile: 16 rows, pitch PP (= 16 mod 32)
+  // P tile (16 a-rows x 128 columns) behind the Q values.  fp64: one 1-KiB DMA instruction per row (16 B per lane),
+  // rows at pitch PP (= 16 mod 32 elements).  fp32: a row is 512 B, so one 16-B-per-lane instruction carries TWO
+  // rows, which land contiguously (LDS-DMA writes lane * 16 B behind a wave-uniform base): the odd row of a pair
+  // is stored with its 16-column halves swapped (column ^ 16, done on the SOURCE address of the lane), which keeps
+  // the operand reads -- 32-lane halves = krow pairs (2j, 2j + 1), ds_read_b32 banks = (a / 4) mod 32 -- conflict
+  // free without padding.  8 instructions per stage instead of 32 four-byte ones: one per wave instead of four.
+  static constexpr int POFF = SLAB + CALS_BN;
   static constexpr int PP = CALS_BN + 16;
-  static constexpr int PLB = (ES == 8) ? 16 : 4;     // bytes per lane of one P DMA instruction
-  static constexpr int PPE = 64 * PLB / ES;          // elements per P DMA instruction: 128 | 64
-  static constexpr int PPR = CALS_BN / PPE;          // instructions per P row: 1 | 2
-  static constexpr int NPP = 16 * PPR / DW;          // P instructions per issuing wave: 2 | 4 (DW = 8)
-  static constexpr int BUF = POFF + 16 * PP;
+  static constexpr int PLB = 16;                     // bytes per lane of one P DMA instruction
+  static constexpr int PPE = 64 * PLB / ES;          // elements per P DMA instruction: 128 (one row) | 256 (two rows)
+  static constexpr int P_INSTR = 16 * CALS_BN / PPE; // 16 | 8 per stage
+  static constexpr int NPP = P_INSTR / DW;           // P instructions per issuing wave: 2 | 1 (DW = 8)
+  static constexpr int PTILE = (ES == 8) ? 16 * PP : 16 * CALS_BN;
+  static constexpr int PQ = (ES == 8) ? 4 * PP : 4 * CALS_BN;  // element offset between the rows of k-steps q, q + 1
+  static constexpr int BUF = POFF + PTILE;
   static constexpr int SP = 144 / ES;                // staging tile pitch: 18 f64 | 36 f32 per column
   static constexpr int STG = 16 * SP;                // per-wave staging tile (T flush transpose)
   static constexpr int LDS_BYTES = (3 * BUF + (ES == 4 ? 8 * STG : 0)) * ES;  // staging: fp32 only
@@ -187,11 +195,16 @@ static __device__ __forceinline__ void run(const TtmArgs &a, const int m0, const
   int p_dst[C::NPP];
 #pragma unroll
   for (int k = 0; k < C::NPP; ++k) {
-    const int pp = k * C::DW + dw;     // P instruction pp: row pp / PPR, columns (pp % PPR) * PPE ...
-    const int row = pp / C::PPR;
-    const int c0 = (pp % C::PPR) * C::PPE;
-    p_src[k] = (unsigned)(row * CALS_BN + c0 + lane * (C::PLB / C::ES)) * (unsigned)C::ES;
-    p_dst[k] = C::POFF + row * C::PP + c0;
+    const int pp = k * C::DW + dw;     // P instruction pp of the stage
+    if constexpr (C::ES == 8) {        // row pp, 2 columns per lane
+      p_src[k] = (unsigned)(pp * CALS_BN + lane * 2) * (unsigned)C::ES;
+      p_dst[k] = C::POFF + pp * C::PP;
+    } else {                           // rows 2 pp (lanes 0-31) and 2 pp + 1 (lanes 32-63, halves swapped), 4 columns per lane
+      const int h = lane >> 5;
+      const int col = ((lane & 31) * 4) ^ (h << 4);
+      p_src[k] = (unsigned)((2 * pp + h) * CALS_BN + col) * (unsigned)C::ES;
+      p_dst[k] = C::POFF + pp * 2 * CALS_BN;
+    }
   }
   long long q_off;
   int q_byte;
@@ -272,7 +285,10 @@ static __device__ __forceinline__ void run(const TtmArgs &a, const int m0, const
   // before merging it: rocprofv3 FETCH_SIZE showed 2.0 GB of fills per launch at C3.)
   const unsigned q_lane_off =
       (unsigned)((C::QOFF + wave * 16 + (C::ES == 8 ? krow : lcol)) * C::ES);
-  const unsigned p_lane_off = (unsigned)((C::POFF + krow * C::PP + wave * 16 + lcol) * C::ES);
+  const unsigned p_lane_off =
+      (C::ES == 8) ? (unsigned)((C::POFF + krow * C::PP + wave * 16 + lcol) * C::ES)
+                   : (unsigned)((C::POFF + (krow >> 1) * 2 * CALS_BN + (krow & 1) * CALS_BN +
+                                 ((wave * 16 + lcol) ^ ((krow & 1) << 4))) * C::ES);
   T *const Tout = static_cast<T *>(a.Tout);
   const bool st = !DIAG(a.dbg & 1) && !STRIP(1);  // CALS_DIAG, dbg 1 (timing only): no T stores
 
@@ -454,9 +470,9 @@ static __device__ __forceinline__ void run(const TtmArgs &a, const int m0, const
       }
       if (!STRIP(256) || iu == 0) {
         lds_read_off<T, 0>(bq[0], bufb + p_lane_off);
-        lds_read_off<T, 4 * C::PP * C::ES>(bq[1], bufb + p_lane_off);
-        lds_read_off<T, 8 * C::PP * C::ES>(bq[2], bufb + p_lane_off);
-        lds_read_off<T, 12 * C::PP * C::ES>(bq[3], bufb + p_lane_off);
+        lds_read_off<T, C::PQ * C::ES>(bq[1], bufb + p_lane_off);
+        lds_read_off<T, 2 * C::PQ * C::ES>(bq[2], bufb + p_lane_off);
+        lds_read_off<T, 3 * C::PQ * C::ES>(bq[3], bufb + p_lane_off);
       }
       P3::template preload<0>(ring, base);
       asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(C::D));  // Q and P landed (D younger reads in flight)

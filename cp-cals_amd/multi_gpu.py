@@ -20,7 +20,10 @@ import torch.distributed as dist
 class WorkQueue:
     """Indices 0 .. n_items-1 handed out in claim order through an atomic counter on a TCPStore."""
 
-    _instances = 0  # queues are constructed collectively (every rank, same order): the n-th one everywhere
+    # default-store queues are constructed collectively (every rank, same order): the n-th one everywhere.  Only those
+    # count -- a queue with an explicit store, a single-process queue or one built before the process group exists
+    # must not shift the key prefix of the ranks that happened to build one.
+    _instances = 0
 
     def __init__(self, n_items, name="cals_work_queue", store=None, port=None):
         """store: any torch.distributed store with add(); default = the process group's own rendezvous
@@ -32,25 +35,46 @@ class WorkQueue:
         self.key = name
         self._local = 0  # single-process fall-back
         self.store = store
-        WorkQueue._instances += 1
+        self._members_ok = True  # default-store queues: checked at the first claim (see _check_members)
         if self.store is None and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             if port is None:
+                WorkQueue._instances += 1
                 get_store = getattr(dist.distributed_c10d, "_get_default_store", None)
                 if get_store is None:
                     raise RuntimeError("this torch build does not expose the process group's store "
                                        "(distributed_c10d._get_default_store): pass store= or port= to WorkQueue")
                 base = get_store()
                 self.store = dist.PrefixStore("cals_work_queue/%d/%s" % (WorkQueue._instances, name), base)
+                self.store.add(self.key + "/members", 1)
+                self._members_ok = False
             else:
                 host = os.environ.get("MASTER_ADDR", "127.0.0.1")
                 self.store = dist.TCPStore(host, int(port), dist.get_world_size(), is_master=(dist.get_rank() == 0),
                                            wait_for_workers=True)
+
+    def _check_members(self, timeout=120.0):
+        """Every rank of the group must count under THIS key: ranks that built a different number of queues would
+        each hand out every index (the work silently done twice).  The first claim waits until all ranks have
+        registered under the prefix and raises if they never do."""
+        world = dist.get_world_size()
+        t_end = time.time() + timeout
+        while True:
+            seen = self.store.add(self.key + "/members", 0)
+            if seen == world:
+                break
+            if seen > world or time.time() > t_end:
+                raise RuntimeError("WorkQueue %r: %d of %d ranks registered under this key prefix -- the ranks did not "
+                                   "construct their work queues in the same order" % (self.key, seen, world))
+            time.sleep(0.01)
+        self._members_ok = True
 
     def claim(self, count):
         """Claims up to `count` indices; returns a (possibly empty) list."""
         count = int(count)
         if count <= 0:
             return []
+        if not self._members_ok:
+            self._check_members()
         if self.store is None:
             lo = self._local
             self._local += count

@@ -74,6 +74,8 @@ def _queue_worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    if rank == 1:  # a queue on a private store, on one rank only, must not shift the shared queues' key prefix
+        assert multi_gpu.WorkQueue(3, store=dist.HashStore()).claim(5) == [0, 1, 2]
     wq = multi_gpu.WorkQueue(57)
     rnd = random.Random(rank)
     got = []

@@ -1,22 +1,19 @@
 #!/bin/bash
 # A/B of prebuilt library variants on the GPU box (no rebuild there): bench.py with the shipped libcals_hip.so,
-# then with every cp-cals_amd/build/variants/libcals_hip_<name>.so copied over it, then the shipped one again.
+# then with every cp-cals_amd/build/variants/libcals_hip_<name>.so, then the shipped one again.  A variant is
+# selected per process (CALS_HIP_LIB, cp_cals_amd.load_library); the shipped library is never overwritten.
 #   bash tools/ab_libs.sh <workload> <out_dir> <name> [<name> ...]
 set -e
 W="${1:-c3}"; OUT="${2:-gpurun_out/ab}"; shift 2
 mkdir -p "$OUT"
-LIB=cp-cals_amd/libcals_hip.so
-cp "$LIB" "$OUT/prod.so.keep"
-run() { python bench.py --workload "$W" --no-cpu-baseline --steady-steps 0 > "$OUT/$1.json" 2> "$OUT/$1.err"; }
+run() { CALS_HIP_LIB="$2" python bench.py --workload "$W" --no-cpu-baseline --no-strong-leg --steady-steps 0 > "$OUT/$1.json" 2> "$OUT/$1.err"; }
 run prod_1
 for v in "$@"; do
-  cp "cp-cals_amd/build/variants/libcals_hip_$v.so" "$LIB"
-  run "${v}_1"
-  run "${v}_2"
+  L="$PWD/cp-cals_amd/build/variants/libcals_hip_$v.so"
+  run "${v}_1" "$L"
+  run "${v}_2" "$L"
 done
-cp "$OUT/prod.so.keep" "$LIB"
 run prod_2
-rm -f "$OUT/prod.so.keep"
 python - "$OUT" prod_1 $(for v in "$@"; do echo ${v}_1 ${v}_2; done) prod_2 <<'PY'
 import json, sys
 for n in sys.argv[2:]:

@@ -2,12 +2,12 @@
 # Timing-only stripping ladder of ttm_kernel at C3: variants compiled with -DCALS_TTM_STRIP=<mask> and prebuilt as
 # cp-cals_amd/build/variants/libcals_hip_strip<mask>.so (bits: ttm_kernel.hip; results of stripped runs are garbage
 # by design -- only the TTM's launch time is read).   bash tools/ttm_strip.sh <out_dir> <mask> [<mask> ...]
+# Every run points its own process at its variant (CALS_HIP_LIB, cp_cals_amd.load_library): the shipped library is
+# never overwritten, so an interrupted ladder leaves nothing behind.
 OUT="${1:-gpurun_out/strip}"; shift
 mkdir -p "$OUT"
-LIB=cp-cals_amd/libcals_hip.so
-cp "$LIB" "$OUT/prod.so.keep"
-run() {
-  python bench.py --workload c3 --no-cpu-baseline --no-strong-leg --steady-steps 0 --steps 20 > "$OUT/strip_$1.json" 2> "$OUT/strip_$1.err"
+run() {  # run <mask> [<library>]
+  CALS_HIP_LIB="$2" python bench.py --workload c3 --no-cpu-baseline --no-strong-leg --steady-steps 0 --steps 20 > "$OUT/strip_$1.json" 2> "$OUT/strip_$1.err"
   python - "$OUT/strip_$1.json" $1 <<'PY'
 import json, sys
 try:
@@ -20,8 +20,6 @@ PY
 }
 run 0
 for m in "$@"; do
-  cp "cp-cals_amd/build/variants/libcals_hip_strip$m.so" "$LIB"
-  run $m
+  run $m "$PWD/cp-cals_amd/build/variants/libcals_hip_strip$m.so"
 done
-cp "$OUT/prod.so.keep" "$LIB"; rm -f "$OUT/prod.so.keep"
 run 0
