@@ -17,7 +17,7 @@ std::vector<int64_t> as_i64(const vector<dim_t> &v) { return std::vector<int64_t
 }  // namespace
 
 MultiKtensor::MultiKtensor(vector<dim_t> &modes_, dim_t buffer_size)
-    : Ktensor(buffer_size, modes_), occupancy(0), occupancy_vec(buffer_size, 0), modes(modes_) {
+    : Ktensor(buffer_size, modes_), col_owner_(buffer_size, 0), mode_sizes_(modes_) {
   for (auto &f : get_factors()) {
     f.zero();  // free columns read as zero (the engine's buffers start zeroed too)
     f.resize(f.get_rows(), 0);
@@ -25,7 +25,7 @@ MultiKtensor::MultiKtensor(vector<dim_t> &modes_, dim_t buffer_size)
 }
 
 int MultiKtensor::check_availability(Ktensor &ktensor) {
-  const auto occ = as_i64(occupancy_vec);
+  const auto occ = as_i64(col_owner_);
   const int64_t pos = cals_hip_host_first_fit(occ.data(), (int64_t)occ.size(), (int64_t)ktensor.get_components());
   if (pos < 0) throw BufferFull();
   return static_cast<int>(pos);
@@ -38,68 +38,68 @@ MultiKtensor &MultiKtensor::add(Ktensor &ktensor) {
   for (auto &f : get_factors()) where[n++] = f.reset_data().get_data() + (dim_t)pos * f.get_col_stride();
   ktensor.attach(where);
 
-  const dim_t id = unique_kt_id++;
+  const dim_t id = next_id_++;
   const dim_t r = ktensor.get_components();
-  for (dim_t c = 0; c < r; c++) occupancy_vec[(dim_t)pos + c] = id;
-  occupancy += static_cast<int>(r);
+  for (dim_t c = 0; c < r; c++) col_owner_[(dim_t)pos + c] = id;
+  cols_in_use_ += static_cast<int>(r);
 
   vector<Matrix> gramians(ktensor.get_n_modes());
   for (auto &g : gramians) g = Matrix(r, r);
   ops::update_gramians(ktensor, gramians);
   ktensor.set_iters(1);
-  if (ktensor.is_jk()) flag_jk = true;
+  if (ktensor.is_jk()) any_jk_ = true;
 
   RegistryEntry entry{ktensor, std::move(gramians), pos, id};
-  if (line_search) {
-    entry.ls_params.prev_ktensor = Ktensor(r, modes);
-    entry.ls_params.backup_ktensor = Ktensor(r, modes);
-    entry.ls_params.cuda = cuda;
-    entry.ls_params.interval = ls_params.interval;
-    entry.ls_params.step = ls_params.step;
-    entry.ls_params.method = ls_params.method;
-    entry.ls_params.T = ls_params.T;
+  if (with_line_search_) {
+    entry.ls_params.prev_ktensor = Ktensor(r, mode_sizes_);
+    entry.ls_params.backup_ktensor = Ktensor(r, mode_sizes_);
+    entry.ls_params.cuda = device_;
+    entry.ls_params.interval = ls_defaults_.interval;
+    entry.ls_params.step = ls_defaults_.step;
+    entry.ls_params.method = ls_defaults_.method;
+    entry.ls_params.T = ls_defaults_.T;
   }
-  registry.insert(std::pair<int, RegistryEntry>(static_cast<int>(id), std::move(entry)));
+  packed_.insert(std::pair<int, RegistryEntry>(static_cast<int>(id), std::move(entry)));
   return adjust_edges();
 }
 
 MultiKtensor &MultiKtensor::remove(dim_t ktensor_id) {
-  RegistryEntry &entry = registry.at(static_cast<int>(ktensor_id));
+  RegistryEntry &entry = packed_.at(static_cast<int>(ktensor_id));
   Ktensor &kt = entry.ktensor;
   kt.detach();  // contents back into the model's own storage, the columns zeroed
-  for (auto &cell : occupancy_vec)
+  for (auto &cell : col_owner_)
     if (cell == ktensor_id) cell = 0;
-  occupancy -= static_cast<int>(kt.get_components());
-  registry.erase(static_cast<int>(ktensor_id));
+  cols_in_use_ -= static_cast<int>(kt.get_components());
+  packed_.erase(static_cast<int>(ktensor_id));
   return adjust_edges();
 }
 
 MultiKtensor &MultiKtensor::adjust_edges() {
-  start = 0;
-  const auto occ = as_i64(occupancy_vec);
-  end = static_cast<int>(cals_hip_host_active_cols(occ.data(), (int64_t)occ.size()));
+  first_col_ = 0;
+  const auto occ = as_i64(col_owner_);
+  width_ = static_cast<int>(cals_hip_host_active_cols(occ.data(), (int64_t)occ.size()));
   for (auto &f : get_factors()) {
-    f.set_data(f.reset_data().get_data() + (dim_t)start * f.get_col_stride());
-    f.resize(f.get_rows(), static_cast<dim_t>(end - start));
+    f.set_data(f.reset_data().get_data() + (dim_t)first_col_ * f.get_col_stride());
+    f.resize(f.get_rows(), static_cast<dim_t>(width_ - first_col_));
   }
   return *this;
 }
 
 MultiKtensor &MultiKtensor::compress() {
-  const auto occ = as_i64(occupancy_vec);
+  const auto occ = as_i64(col_owner_);
   std::vector<int64_t> ids(occ.size()), offs(occ.size());
   const int64_t n_moves =
       cals_hip_host_compress_plan(occ.data(), (int64_t)occ.size(), ids.data(), offs.data(), (int64_t)occ.size());
   vector<double *> where(get_n_modes());
   for (int64_t k = 0; k < n_moves; k++) {  // left to right, as the reference applies them
-    RegistryEntry &entry = registry.at(static_cast<int>(ids[(size_t)k]));
+    RegistryEntry &entry = packed_.at(static_cast<int>(ids[(size_t)k]));
     Ktensor &kt = entry.ktensor;
     const dim_t off = (dim_t)offs[(size_t)k];
     dim_t n = 0;
     for (auto &f : kt.get_factors()) where[n++] = f.get_data() - off * f.get_col_stride();
     kt.attach(where, kt.get_components() < off);  // overlapping moves are handled inside attach (memmove)
     for (dim_t c = (dim_t)entry.col; c < (dim_t)entry.col + kt.get_components(); c++)
-      std::swap(occupancy_vec[c - off], occupancy_vec[c]);
+      std::swap(col_owner_[c - off], col_owner_[c]);
     entry.col -= static_cast<int>(off);
   }
   return adjust_edges();

@@ -34,17 +34,18 @@ struct BufferFull : public std::exception {  // include/multi_ktensor.h:123-127
 };
 
 class MultiKtensor : public Ktensor {
-  int occupancy{0};
-  int start{0};
-  int end{0};
-  vector<dim_t> occupancy_vec;  // id of the model in every column, 0 = free
-  vector<dim_t> modes;
-  Registry registry;
-  bool cuda{false};
-  bool line_search{false};
-  ls::LineSearchParams ls_params{};
-  bool flag_jk = false;
-  dim_t unique_kt_id{1};
+  // packing state (own layout; the public interface below is the reference's)
+  Registry packed_;                  // in-flight models by id
+  vector<dim_t> col_owner_;          // id of the model in every column, 0 = free
+  vector<dim_t> mode_sizes_;
+  dim_t next_id_{1};
+  int cols_in_use_{0};
+  int first_col_{0}, width_{0};      // active window of the buffer: columns [first_col_, width_)
+  bool any_jk_ = false;
+  // what add() copies into a model's RegistryEntry
+  bool device_{false};
+  bool with_line_search_{false};
+  ls::LineSearchParams ls_defaults_{};
 
   int check_availability(Ktensor &ktensor);  // first fit; throws BufferFull
   MultiKtensor &adjust_edges();
@@ -65,14 +66,14 @@ class MultiKtensor : public Ktensor {
   // shift the surviving models left over the gaps (src/multi_ktensor.cpp:188-264)
   MultiKtensor &compress();
 
-  Registry &get_registry() { return registry; }
-  [[nodiscard]] int get_start() const noexcept { return start; }
-  [[nodiscard]] bool get_flag_jk() const noexcept { return flag_jk; }
-  void set_cuda(bool value) { cuda = value; }
-  void set_line_search(bool value) { line_search = value; }
-  void set_line_search_params(ls::LineSearchParams &params) { ls_params = params; }
-  [[maybe_unused]] vector<dim_t> &get_modes() { return modes; }
-  int get_leftmost_id() { return occupancy_vec.empty() ? -1 : static_cast<int>(occupancy_vec[0]); }
+  Registry &get_registry() { return packed_; }
+  [[nodiscard]] int get_start() const noexcept { return first_col_; }
+  [[nodiscard]] bool get_flag_jk() const noexcept { return any_jk_; }
+  void set_cuda(bool value) { device_ = value; }
+  void set_line_search(bool value) { with_line_search_ = value; }
+  void set_line_search_params(ls::LineSearchParams &params) { ls_defaults_ = params; }
+  [[maybe_unused]] vector<dim_t> &get_modes() { return mode_sizes_; }
+  int get_leftmost_id() { return col_owner_.empty() ? -1 : static_cast<int>(col_owner_[0]); }
 };
 }  // namespace cals
 #endif

@@ -169,6 +169,7 @@ struct cals_hip_engine {
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   double *nnls_hscratch = nullptr;  // ... and the blocks of nnls_huge_kernel
   size_t nnls_hblocks = 0;
+  int nnls_chunk_cap = 0;      // workgroups per model the scratch was sized for (0: nnls_huge_chunks decides)
   int *d_hcounter = nullptr;
   void *krp_ws = nullptr;
   size_t krp_elems = 0;
@@ -187,6 +188,7 @@ struct cals_hip_engine {
   ModelTable mt{};
   int max_slots = 0;
   int *d_slots = nullptr;
+  int4 *d_wgdesc = nullptr;   // {slot, column, rank, jackknife} per registry position (UpdateArgs::wgdesc)
   int *d_cls_idx = nullptr;   // registry positions sorted by NNLS rank class (nnls_rank_class): a class launch's
   int cls_off[8] = {0};       // workgroups are exactly its models -- positions [cls_off[k], cls_off[k + 1])
   bool slots_dirty = true;
@@ -432,6 +434,14 @@ int upload_slots(cals_hip_engine *e) {
     size_t k = 0;
     for (auto t : e->registry) s[k++] = e->models[t].slot;
     HIPCHK(hipMemcpyAsync(e->d_slots, s, k * sizeof(int), hipMemcpyHostToDevice, e->stream));
+    int4 *wd = nullptr;
+    if ((rc = arena_alloc(e, e->registry.size() * sizeof(int4), (void **)&wd))) return rc;
+    k = 0;
+    for (auto t : e->registry) {
+      const HostModel &m = e->models[t];
+      wd[k++] = make_int4(m.slot, (int)m.col, (int)m.rank, upd_jk_pack(m.jk_mode, m.jk_fiber));
+    }
+    HIPCHK(hipMemcpyAsync(e->d_wgdesc, wd, k * sizeof(int4), hipMemcpyHostToDevice, e->stream));
     // the same registry positions grouped by rank class (counting sort, registry order kept inside a class)
     int *ci = nullptr;
     if ((rc = arena_alloc(e, e->registry.size() * sizeof(int), (void **)&ci))) return rc;
@@ -1001,16 +1011,38 @@ int sweep_once(cals_hip_engine *e, bool evict_enabled, bool defer_changed = fals
     rank_classes |= 1u << nnls_rank_class(rk);
   }
   if (n_huge || n_pipe) {
-    if (e->prm.update_method == 1) {  // nnls_huge_kernel: H and the waves' Cholesky factors, per workgroup
+    if (e->prm.update_method == 1 && n_huge) {  // nnls_huge_kernel: H and the waves' Cholesky factors, per workgroup
+      // One row per wavefront where memory allows (nnls_huge_chunks: up to 16 GiB); with X, T and the line-search
+      // copies resident that much may not be free -- the launch then gets fewer, longer workgroups per model
+      // (NnlsArgs::huge_chunk_cap) instead of the sweep failing: bounded by the free memory minus a margin first,
+      // halved on an out-of-memory answer after that.
       int chunks = 1;
       for (int n = 0; n < e->n_modes; n++) chunks = std::max(chunks, nnls_huge_chunks((int)e->modes[n], (int)n_huge));
-      const size_t need = n_huge * (size_t)chunks;
-      if (need > e->nnls_hblocks) {
+      const int want = chunks;
+      if (e->nnls_chunk_cap > 0) chunks = std::min(chunks, e->nnls_chunk_cap);
+      if (n_huge * (size_t)chunks > e->nnls_hblocks) {
+        chunks = want;  // sized anew: an earlier cap belonged to an earlier set of models
         if (e->nnls_hscratch) HIPCHK(hipFree(e->nnls_hscratch));
         e->nnls_hscratch = nullptr;
         e->nnls_hblocks = 0;
-        HIPCHK(cals_malloc((void **)&e->nnls_hscratch, need * nnls_huge_block_doubles() * sizeof(double)));
-        e->nnls_hblocks = need;
+        const size_t block_bytes = nnls_huge_block_doubles() * sizeof(double);
+        size_t free_b = 0, total_b = 0;
+        HIPCHK(hipMemGetInfo(&free_b, &total_b));
+        const size_t margin = (size_t)1 << 30;
+        const size_t fit = free_b > margin ? (free_b - margin) / (block_bytes * n_huge) : 0;
+        chunks = (int)std::max<size_t>(1, std::min<size_t>((size_t)chunks, fit));
+        for (;;) {
+          const hipError_t rc_alloc = cals_malloc((void **)&e->nnls_hscratch, n_huge * (size_t)chunks * block_bytes);
+          if (rc_alloc == hipSuccess) break;
+          (void)hipGetLastError();
+          e->nnls_hscratch = nullptr;
+          if (rc_alloc != hipErrorOutOfMemory || chunks == 1)
+            return fail(e, CALS_HIP_ERR_HIP, "cannot allocate the scratch of the NNLS update for ranks above 64 (" +
+                                                 std::to_string(n_huge * (size_t)chunks * block_bytes >> 20) + " MiB)");
+          chunks = (chunks + 1) / 2;
+        }
+        e->nnls_hblocks = n_huge * (size_t)chunks;
+        e->nnls_chunk_cap = chunks < want ? chunks : 0;
       }
     }
     if (e->prm.update_method != 1) {  // huge_solve_kernel's <z, z> per row, [n_pipe][I]
@@ -1051,6 +1083,7 @@ int sweep_once(cals_hip_engine *e, bool evict_enabled, bool defer_changed = fals
     Geo g{0, 0};
     UpdateArgs u{};
     u.slots = e->d_slots;
+    u.wgdesc = e->d_wgdesc;
     u.n_slots = ns;
     u.mt = e->mt;
     u.factor = e->factor[n];
@@ -1175,6 +1208,7 @@ int sweep_once(cals_hip_engine *e, bool evict_enabled, bool defer_changed = fals
       for (int c = 0; c < 8; c++) q.cls_off[c] = e->cls_off[c];
       q.dbg_counts = e->dbg_trace ? e->dbg_trace + 8 * 2048 + 1024 : nullptr;  // CALS_DIAG + CALS_TTM_TRACE: row / solve counters
       q.hscratch = e->nnls_hscratch;
+      q.huge_chunk_cap = e->nnls_chunk_cap;
       q.hcounter = e->d_hcounter;
       if (n_huge) HIPCHK(hipMemsetAsync(e->d_hcounter, 0, sizeof(int), e->stream));  // nnls_huge_kernel's blocks
       HIPCHK(nnls_launch(q, e->stream));
@@ -1429,6 +1463,7 @@ int compress(cals_hip_engine *e) {
   }
   tree_invalidate(e);
   pt_invalidate(e);
+  e->slots_dirty = true;  // the models' first columns change: UpdateArgs::wgdesc carries them
   // host bookkeeping request by request (as the reference applies them, left to right); the column
   // traffic of ALL requests and ALL buffers then goes out as one gather + one scatter launch
   std::vector<int> src, dst, pairs;
@@ -1960,6 +1995,7 @@ int cals_hip_create_ex(cals_hip_engine **out, int n_modes, const int64_t *modes,
   if ((rc = dev_alloc(e, &e->mt.bk_iters, ms))) return rc;
   if ((rc = dev_alloc(e, &e->mt.flags, ms))) return rc;
   if ((rc = dev_alloc(e, &e->d_slots, ms))) return rc;
+  if ((rc = dev_alloc(e, &e->d_wgdesc, ms))) return rc;
   if ((rc = dev_alloc(e, &e->d_cls_idx, ms))) return rc;
   if ((rc = dev_alloc(e, &e->d_jk_norms, (size_t)modes[0]))) return rc;
   e->h_flags.assign(ms, 0);
@@ -2120,6 +2156,7 @@ int cals_hip_destroy(cals_hip_engine *e) {
   fr(e->mt.bk_iters);
   fr(e->mt.flags);
   fr(e->d_slots);
+  fr(e->d_wgdesc);
   fr(e->d_cls_idx);
   for (auto &p : e->ev_pool) {
     (void)hipEventDestroy(p.a);

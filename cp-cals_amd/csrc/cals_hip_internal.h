@@ -137,8 +137,12 @@ struct ModelTable {
 
 // smallest rank whose unconstrained update runs as the pipeline of huge_* launches (33 | 49 | 65; measured)
 #define CALS_HUGE_FROM_DEFAULT 33
+// jackknife descriptor of a model in one int: -1 = regular model, else (fiber << 3) | mode
+inline int upd_jk_pack(int jk_mode, long long jk_fiber) { return jk_mode < 0 ? -1 : (int)((jk_fiber << 3) | jk_mode); }
 struct UpdateArgs {
   const int *slots;    // active slots, one wave each
+  const int4 *wgdesc;  // per registry position {slot, first column, rank, upd_jk_pack}: what the rank <= CALS_RFAST
+                       // kernels need to start, in one load (kept current by the engine: upload_slots)
   int n_slots;
   ModelTable mt;
   void *factor;        // multi-factor of this mode (element type = dtype), I x buffer, ld = I
@@ -219,7 +223,8 @@ struct NnlsArgs {
   int rlo, rhi;        // set by nnls_launch: the ranks this launch serves
   int chunks;          // set by nnls_launch: workgroups per model
   unsigned long long *dbg_counts;  // CALS_DIAG builds: {rows, solves, factorisations, main-loop passes, inner passes}
-  double *hscratch;    // models above CALS_RMAX: n_huge * nnls_huge_chunks(I, n_huge) blocks of nnls_huge_block_doubles()
+  int huge_chunk_cap;  // > 0: at most this many workgroups per model of rank > CALS_RMAX (the engine's scratch holds no more)
+  double *hscratch;    // models above CALS_RMAX: n_huge * min(nnls_huge_chunks(I, n_huge), huge_chunk_cap) blocks of nnls_huge_block_doubles()
   int *hcounter;       // zero at launch: blocks are handed out in arrival order
 };
 hipError_t nnls_launch(const NnlsArgs &a, hipStream_t st);

@@ -273,13 +273,12 @@ static_assert(sizeof(double) * (16 * 17) <= sizeof(double) * CALS_RFAST * CALS_R
 // callee-saved registers it saved on entry (47 scratch loads + a wait at rank 20) for a caller that ends at once.
 #define UPD_BODY_ATTR __attribute__((noinline, noreturn))
 template <int RMAX, typename T>
-static __device__ UPD_BODY_ATTR void update_body(UpdArgsPtr a_ptr, int slot, int r,
+static __device__ UPD_BODY_ATTR void update_body(UpdArgsPtr a_ptr, int slot, int r, int col, int jkp,
                                                       UpdShared &sh) {
   UpdArgsRef a = upd_uniform(a_ptr);  // the calling kernel's argument block (constant memory, scalar loads)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int col = a.mt.col[slot];
   const long long iters = a.mt.iters[slot];
-  const int jkf = (a.mt.jk_mode[slot] == a.mode) ? a.mt.jk_fiber[slot] : -1;
+  const int jkf = (jkp >= 0 && (jkp & 7) == a.mode) ? (jkp >> 3) : -1;  // jkp: upd_jk_pack
   const int I = a.I;
   double *Hs = sh.Hs;
 
@@ -541,8 +540,7 @@ static __device__ UPD_BODY_ATTR void update_body(UpdArgsPtr a_ptr, int slot, int
     __syncthreads();
     if (tid == 0) {
       t2 = sh.redt[0] + sh.redt[1] + sh.redt[2] + sh.redt[3];
-      const int jm = a.mt.jk_mode[slot];
-      const double xn = (jm >= 0) ? a.jk_norms[a.mt.jk_fiber[slot]] : a.X_norm;
+      const double xn = (jkp >= 0) ? a.jk_norms[jkp >> 3] : a.X_norm;
       const double e2 = fmax(xn * xn + t2 - 2.0 * t3, 0.0);
       const double err = sqrt(e2);
       a.mt.err[slot] = err;
@@ -568,13 +566,12 @@ static __device__ UPD_BODY_ATTR void update_body(UpdArgsPtr a_ptr, int slot, int
 extern __shared__ __attribute__((aligned(16))) unsigned char upd_dyn[];
 
 template <int RMAX, typename T>
-static __device__ UPD_BODY_ATTR void update_body_lds(UpdArgsPtr a_ptr, int slot, int r,
-                                                          UpdShared &sh) {
+static __device__ UPD_BODY_ATTR void update_body_lds(UpdArgsPtr a_ptr, int slot, int r, int col, int jkp,
+                                                      UpdShared &sh) {
   UpdArgsRef a = upd_uniform(a_ptr);  // the calling kernel's argument block (constant memory, scalar loads)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int col = a.mt.col[slot];
   const long long iters = a.mt.iters[slot];
-  const int jkf = (a.mt.jk_mode[slot] == a.mode) ? a.mt.jk_fiber[slot] : -1;
+  const int jkf = (jkp >= 0 && (jkp & 7) == a.mode) ? (jkp >> 3) : -1;  // jkp: upd_jk_pack
   const int I = a.I;
   const int xld = a.xld;
   double *Hs = sh.Hs;
@@ -721,67 +718,57 @@ static __device__ UPD_BODY_ATTR void update_body_lds(UpdArgsPtr a_ptr, int slot,
   t3 = sh.redt[0] + sh.redt[1] + sh.redt[2] + sh.redt[3];
   UPD_STAMP(3);
 
-  // column scales (Ktensor::normalize(mode, iteration), src/ktensor.cpp:66-83): wave w owns columns
-  // w, w + 4, ...; first sweep of a model: 2-norm; later: the entry of largest magnitude, first
-  // index on ties (cblas_idamax), with its sign
+  // column scales (Ktensor::normalize(mode, iteration), src/ktensor.cpp:66-83): first sweep of a model: 2-norm;
+  // later: the entry of largest magnitude, first index on ties (cblas_idamax), with its sign.
+  // Thread (c = tid % LC, chunk = tid / LC) walks rows [chunk * CH, (chunk + 1) * CH) of column c of the LDS panel in
+  // ascending order (LC = 8 | 16 | 32 columns per chunk by rank class: the fewer columns, the more and shorter chunks;
+  // odd xld: the columns of a chunk sit on different banks), thread c then folds the chunk results in chunk order --
+  // "strictly larger wins" in ascending row order IS idamax's first-index rule, no index comparison and no
+  // cross-lane shuffle anywhere.  (Round 3: wave = column group, lanes over rows, six butterfly steps of three
+  // 64-bit shuffles per column: 11.8 K of the body's 48.7 K cycles at C2.)
   {
-    constexpr int NC = (RMAX + UPD_WAVES - 1) / UPD_WAVES;  // columns wave, wave + 4, ... of this wave
-    double m[NC], v[NC];
-    int ix[NC];
-#pragma unroll
-    for (int q = 0; q < NC; ++q) {
-      m[q] = first ? 0.0 : -1.0;
-      v[q] = 0.0;
-      ix[q] = 0x7fffffff;
-    }
-    for (int i = lane; i < I; i += 64) {
-#pragma unroll
-      for (int q = 0; q < NC; ++q) {
-        const int c = wave + UPD_WAVES * q;
-        if (c < r) {
-          const double x = (double)xs[i + xld * c];
-          if (first) {
-            m[q] += x * x;
-          } else {
-            const double ax = fabs(x);
-            if (ax > m[q]) {
-              m[q] = ax;
-              v[q] = x;
-              ix[q] = i;
-            }
+    constexpr int LC = RMAX <= 8 ? 8 : RMAX <= 16 ? 16 : 32;
+    constexpr int NCH = UPD_THREADS / LC;
+    double *pm = &sh.gp[0][0][0];                // [NCH][LC] chunk maxima / sums   (H, L, 1/diagonal are dead:
+    double *pv = pm + UPD_THREADS;               // [NCH][LC] signed entry there     every thread passed the barrier
+    const int c = tid % LC, chunk = tid / LC;    //                                  behind the row solves)
+    const int CH = (I + NCH - 1) / NCH;
+    const int i0 = chunk * CH, i1 = min(I, i0 + CH);
+    double m = first ? 0.0 : -1.0, v = 0.0;
+    if (c < r) {
+      const T *xc = xs + xld * c;
+      for (int i = i0; i < i1; ++i) {
+        const double x = (double)xc[i];
+        if (first) {
+          m += x * x;
+        } else {
+          const double ax = fabs(x);
+          if (ax > m) {
+            m = ax;
+            v = x;
           }
         }
       }
+      pm[chunk * LC + c] = m;
+      pv[chunk * LC + c] = v;
     }
-    if (first) {
+    __syncthreads();
+    if (tid < r) {
+      double mm = pm[tid], vv = pv[tid];
 #pragma unroll
-      for (int off = 32; off > 0; off >>= 1)
-#pragma unroll
-        for (int q = 0; q < NC; ++q) m[q] += __shfl_xor(m[q], off);
-    } else {
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1)
-#pragma unroll
-        for (int q = 0; q < NC; ++q) {
-          const double m2 = __shfl_xor(m[q], off);
-          const double v2 = __shfl_xor(v[q], off);
-          const int i2 = __shfl_xor(ix[q], off);
-          const bool take = (m2 > m[q]) || (m2 == m[q] && i2 < ix[q]);
-          m[q] = take ? m2 : m[q];
-          v[q] = take ? v2 : v[q];
-          ix[q] = take ? i2 : ix[q];
-        }
-    }
-    if (lane == 0) {
-#pragma unroll
-      for (int q = 0; q < NC; ++q) {
-        const int c = wave + UPD_WAVES * q;
-        if (c < r) {
-          const double lam = first ? sqrt(m[q]) : v[q];
-          sh.lams[c] = lam;
-          a.lambda[col + c] = lam;
+      for (int k = 1; k < NCH; ++k) {
+        const double m2 = pm[k * LC + tid];
+        if (first) {
+          mm += m2;
+        } else if (m2 > mm) {
+          mm = m2;
+          vv = pv[k * LC + tid];
         }
       }
+      const double lam = first ? sqrt(mm) : vv;
+      sh.lams[tid] = lam;
+      sh.lams[CALS_RFAST + tid] = (lam != 0.0) ? 1.0 / lam : 1.0;  // cblas_dscal by 1 / lambda, skipped for lambda == 0
+      a.lambda[col + tid] = lam;
     }
   }
   __syncthreads();
@@ -789,14 +776,13 @@ static __device__ UPD_BODY_ATTR void update_body_lds(UpdArgsPtr a_ptr, int slot,
   UPD_STAMP(5);
 
   // cblas_dscal by 1/lambda (skipped for lambda == 0): the normalised factor goes to HBM once and
-  // stays in LDS (rounded to the storage type) for the Gramian
-  for (int i = tid; i < I; i += UPD_THREADS) {
+  // stays in LDS (rounded to the storage type) for the Gramian.  Thread (row = tid & 127, column parity = tid >> 7).
+  for (int i = tid & 127; i < I; i += 128) {
 #pragma unroll
-    for (int c = 0; c < RMAX; ++c) {
+    for (int c0 = 0; c0 < RMAX; c0 += 2) {
+      const int c = c0 + (tid >> 7);
       if (c < r) {
-        const double lam = lams[c];
-        T v = xs[i + xld * c];
-        if (lam != 0.0) v = (T)((1.0 / lam) * (double)v);
+        const T v = (T)(lams[CALS_RFAST + c] * (double)xs[i + xld * c]);
         fac[i + (long long)I * c] = v;
         xs[i + xld * c] = v;
       }
@@ -860,8 +846,7 @@ static __device__ UPD_BODY_ATTR void update_body_lds(UpdArgsPtr a_ptr, int slot,
     __syncthreads();
     if (tid == 0) {
       t2 = sh.redt[0] + sh.redt[1] + sh.redt[2] + sh.redt[3];
-      const int jm = a.mt.jk_mode[slot];
-      const double xn = (jm >= 0) ? a.jk_norms[a.mt.jk_fiber[slot]] : a.X_norm;
+      const double xn = (jkp >= 0) ? a.jk_norms[jkp >> 3] : a.X_norm;
       const double e2 = fmax(xn * xn + t2 - 2.0 * t3, 0.0);
       const double err = sqrt(e2);
       a.mt.err[slot] = err;
@@ -1364,19 +1349,19 @@ static __device__ UPD_BODY_ATTR void update_body_huge(UpdArgsPtr a_ptr, int slot
 #define UPD_DISPATCH(BODY)                      \
   do {                                          \
     if (r <= 4)                                 \
-      BODY<4, T>(a_ptr, slot, r, sh);               \
+      BODY<4, T>(a_ptr, slot, r, col, jkp, sh);     \
     else if (r <= 8)                            \
-      BODY<8, T>(a_ptr, slot, r, sh);               \
+      BODY<8, T>(a_ptr, slot, r, col, jkp, sh);     \
     else if (r <= 12)                           \
-      BODY<12, T>(a_ptr, slot, r, sh);              \
+      BODY<12, T>(a_ptr, slot, r, col, jkp, sh);    \
     else if (r <= 16)                           \
-      BODY<16, T>(a_ptr, slot, r, sh);              \
+      BODY<16, T>(a_ptr, slot, r, col, jkp, sh);    \
     else if (r <= 20)                           \
-      BODY<20, T>(a_ptr, slot, r, sh);              \
+      BODY<20, T>(a_ptr, slot, r, col, jkp, sh);    \
     else if (r <= 24)                           \
-      BODY<24, T>(a_ptr, slot, r, sh);              \
+      BODY<24, T>(a_ptr, slot, r, col, jkp, sh);    \
     else                                        \
-      BODY<32, T>(a_ptr, slot, r, sh);              \
+      BODY<32, T>(a_ptr, slot, r, col, jkp, sh);    \
   } while (0)
 
 template <typename T>
@@ -1385,8 +1370,11 @@ __global__ void __launch_bounds__(UPD_THREADS, 2) update_lds_kernel(const Update
   UpdArgsPtr a_ptr = upd_kernargs();
   UpdArgsRef a = *a_ptr;
   __shared__ UpdShared sh;
-  const int slot = a.slots[blockIdx.x];
-  const int r = a.mt.rank[slot];
+  // {slot, first column, rank, jackknife (mode, fiber) packed} of this workgroup's model in ONE load (UpdateArgs::
+  // wgdesc, written by the engine with the slot list): slot -> rank -> column were three dependent round trips in
+  // front of the first Gramian load
+  const int4 d = a.wgdesc[blockIdx.x];
+  const int slot = d.x, col = d.y, r = d.z, jkp = d.w;
   if (r > CALS_RFAST) return;
   UPD_DISPATCH(update_body_lds);
 }
@@ -1397,8 +1385,11 @@ __global__ void __launch_bounds__(UPD_THREADS, 2) update_hbm_kernel(const Update
   UpdArgsPtr a_ptr = upd_kernargs();
   UpdArgsRef a = *a_ptr;
   __shared__ UpdShared sh;
-  const int slot = a.slots[blockIdx.x];
-  const int r = a.mt.rank[slot];
+  // {slot, first column, rank, jackknife (mode, fiber) packed} of this workgroup's model in ONE load (UpdateArgs::
+  // wgdesc, written by the engine with the slot list): slot -> rank -> column were three dependent round trips in
+  // front of the first Gramian load
+  const int4 d = a.wgdesc[blockIdx.x];
+  const int slot = d.x, col = d.y, r = d.z, jkp = d.w;
   if (r > CALS_RFAST) return;
   UPD_DISPATCH(update_body);
 }

@@ -1353,6 +1353,7 @@ hipError_t nnls_launch(const NnlsArgs &a_in, hipStream_t st) {
     }
     a.n_cls = n_models;
     a.chunks = nnls_huge_chunks(a.I, std::max(n_models, 1));
+    if (a.huge_chunk_cap > 0) a.chunks = std::min(a.chunks, a.huge_chunk_cap);
     const dim3 hgrid((unsigned)(std::max(n_models, 1) * a.chunks)), hblock(64 * NNLS_HWAVES);
     if (di)
       hipLaunchKernelGGL(nnls_huge_kernel<float>, hgrid, hblock, 0, st, a);
