@@ -578,112 +578,54 @@ static __device__ UPD_BODY_ATTR void update_body_lds(UpdArgsPtr a_ptr, int slot,
   T *xs = reinterpret_cast<T *>(upd_dyn);  // I x r panel, ld = xld (storage type, like the factor)
 
   UPD_STAMP(0);
-  // H = hadamard of the other modes' Gramians (hadamard_but_one), PADDED to RMAX x RMAX with the identity:
-  // the factorisation below then runs over RMAX columns without a single `c < r` guard (r reaches this
-  // non-inlined function in a VGPR, so every guard is an exec-mask save / restore + branch around one FMA).
-  // The padding contributes exact zeros: L comes out as diag(L_r, I).  (The row solves keep their guards:
-  // without them the allocator spills x[] -- measured 11.2 K -> 15.7 K cycles per pass at rank 20.)
-  for (int e = tid; e < RMAX * RMAX; e += UPD_THREADS) {
-    const int i = e % RMAX, j = e / RMAX;
-    double h = (i == j) ? 1.0 : 0.0;
-    if (i < r && j < r) {
-      h = 1.0;
-      for (int m = 0; m < a.n_modes; ++m)
-        if (m != a.mode) h *= a.gram[m][i + CALS_GLD * (long long)(col + j)];
-    }
-    Hs[i + RMAX * j] = h;
-  }
-  __syncthreads();
-  UPD_STAMP(1);
-
   // NNLS update: the panel already holds the constrained solution (nnls_kernel.hip)
   const double *rowdot = a.rowdot ? a.rowdot + (long long)I * blockIdx.x : nullptr;
   const bool solved = rowdot != nullptr;
-  // dpotrf('L') restated as unblocked dpotf2 on wave 0, lane = row, the row held in REGISTERS: the
-  // entries L[j][k] that the column update needs from row j come through v_readlane (j and k are
-  // compile-time after unrolling), so the factorisation touches LDS only to load H and to store L.
-  // (With the rows in LDS every column cost two dependent LDS round trips per 4 k: 22.9 K of the
-  // kernel's 64 K cycles at rank 20.)  Same operations in the same order as before: for column j,
-  // s_i = H[i][j] - L[i][0] L[j][0] - ... - L[i][j-1] L[j][j-1] for every row i >= j; ajj = s_j.
-  // info != 0: stop, keep going with whatever is in H, as the reference does (update.cpp:183-185
-  // only logs).
-  if (wave == 0 && !solved) {
-    double Lr[RMAX];
-    const int li = lane < RMAX ? lane : 0;
-#pragma unroll
-    for (int c = 0; c < RMAX; ++c) Lr[c] = Hs[li + RMAX * c];
-    int info = 0;
-    // RIGHT-looking form of the same factorisation: as soon as column j is final, every later column k
-    // of the row takes its term  A[i][k] -= L[i][j] L[k][j]  -- the terms of an entry still arrive in the
-    // order j = 0, 1, ... with the same operands as in dpotf2's left-looking sum, but the RMAX - j - 1
-    // updates of a column step are independent of each other (the left-looking form chained j dependent
-    // FMAs in front of every pivot).  L[k][j] comes from lane k by v_readlane.
-    // The pivot costs one 1/sqrt: l_jj = a * y, column = s * y with y = 1/sqrt(a) from v_rsq_f64 + two
-    // Newton steps and a final correction of l_jj.  Entries differ from IEEE sqrt / divide by at most an
-    // ulp or two -- far inside the 1e-12 the kernel tests hold against the oracle.
-#pragma unroll
-    for (int j = 0; j < RMAX; ++j) {
-      if (info == 0) {
-        const double ajj = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(Lr[j]), j),
-                                            __builtin_amdgcn_readlane(__double2loint(Lr[j]), j));
-        if (!(ajj > 0.0)) {
-          info = j + 1;  // lane j keeps a_jj in Lr[j], as dpotf2 leaves it (only a real column can fail)
-        } else {
-#if CALS_CHOL_EXACT
-          const double ljj = sqrt(ajj);
-          const double cj = Lr[j] / ljj;
-#else
-          double y = __builtin_amdgcn_rsq(ajj);
-          y = y * fma(-0.5 * ajj * y, y, 1.5);
-          y = y * fma(-0.5 * ajj * y, y, 1.5);
-          double ljj = ajj * y;
-          ljj = fma(0.5 * y, fma(-ljj, ljj, ajj), ljj);
-          const double cj = Lr[j] * y;
-#endif
-          Lr[j] = (lane == j) ? ljj : ((lane > j) ? cj : Lr[j]);
-#pragma unroll
-          for (int k = j + 1; k < RMAX; ++k) {
-            const double lkj = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(Lr[j]), k),
-                                                __builtin_amdgcn_readlane(__double2loint(Lr[j]), k));
-            Lr[k] -= Lr[j] * lkj;
-          }
-        }
-      }
-    }
-    if (lane < RMAX) {
-#pragma unroll
-      for (int c = 0; c < RMAX; ++c)
-        if (c <= lane) Hs[lane + RMAX * c] = Lr[c];
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    if (lane < RMAX) sh.dinv[lane] = 1.0 / Hs[lane + RMAX * lane];
-    if (lane == 0) a.mt.potrf_info[slot] = info;
-  }
-  __syncthreads();
   const double *dinv = sh.dinv;
-  UPD_STAMP(2);
-
   T *fac = static_cast<T *>(a.factor) + (long long)I * col;
   const bool first = (iters == 1);
   double t3 = 0.0;
+  // The factorisation publishes L in panels of PW columns; the rows' forward substitution follows it panel by panel
+  constexpr int PW = 4;
+  static_assert(RMAX % PW == 0, "rank classes are multiples of the panel width");
 
-  // rows: G row -> two triangular solves -> unnormalised factor row, into the LDS panel
-  for (int i = tid; i < I; i += UPD_THREADS) {
+  // One row: G row -> two triangular solves -> unnormalised factor row, into the LDS panel.
+  // PIPE (waves 1-3 while wave 0 factors): barrier p of the workgroup says "columns PW p .. PW p + PW - 1 of L are in
+  // LDS"; step k of the forward substitution B := B inv(L^T) needs column k and nothing else, so the rows take a
+  // panel's steps right behind its barrier and then wait for the next panel -- a step is ~80 cycles, a column of
+  // the factorisation ~500: the forward solve and the load of the G rows hide behind the factorisation.  1 / l_kk is
+  // divided out by the row itself there (same value as dinv, which exists only behind the last barrier).
+  auto solve_row = [&]<bool PIPE>(int i, bool valid) {
     double x[RMAX], g[RMAX];
     asm volatile("" ::: "memory");  // keep L in LDS (see update_body)
-    upd_load_g_row<RMAX, T>(a, fac, i, I, col, r, x);
+    if (valid) {
+      upd_load_g_row<RMAX, T>(a, fac, i, I, col, r, x);
+    } else {
+#pragma unroll
+      for (int c = 0; c < RMAX; ++c) x[c] = 0.0;
+    }
 #pragma unroll
     for (int c = 0; c < RMAX; ++c) g[c] = x[c];
     if (!solved) {
 #pragma unroll
       for (int k = 0; k < RMAX; ++k) {
+        if constexpr (PIPE) {
+          if (k % PW == 0) {
+            __syncthreads();  // barrier k / PW
+            asm volatile("" ::: "memory");
+          }
+        }
         if (k < r) {
-          x[k] = dinv[k] * x[k];
+          const double dk = PIPE ? 1.0 / Hs[k + RMAX * k] : dinv[k];
+          x[k] = dk * x[k];
 #pragma unroll
           for (int j = k + 1; j < RMAX; ++j)
             if (j < r) x[j] -= Hs[j + RMAX * k] * x[k];
         }
+      }
+      if constexpr (PIPE) {
+        __syncthreads();  // barrier NPAN: 1 / diagonal is in LDS, the factorisation is through
+        asm volatile("" ::: "memory");
       }
 #pragma unroll
       for (int j = RMAX - 1; j >= 0; --j) {
@@ -702,16 +644,117 @@ static __device__ UPD_BODY_ATTR void update_body_lds(UpdArgsPtr a_ptr, int slot,
     if (solved) {  // <x, g> of this row as nnls_kernel left it; g itself is gone
 #pragma unroll
       for (int c = 0; c < RMAX; ++c) g[c] = 0.0;
-      if (i != jkf) t3 += rowdot[i];
+      if (valid && i != jkf) t3 += rowdot[i];
     }
+    if (valid) {
 #pragma unroll
-    for (int c = 0; c < RMAX; ++c) {
-      if (c < r) {
-        xs[i + xld * c] = (T)x[c];
-        t3 += x[c] * g[c];
+      for (int c = 0; c < RMAX; ++c) {
+        if (c < r) {
+          xs[i + xld * c] = (T)x[c];
+          t3 += x[c] * g[c];
+        }
       }
     }
+  };
+
+  if (!solved) {
+    if (wave == 0) {
+      // H = hadamard of the other modes' Gramians (hadamard_but_one), lane = row, the row in REGISTERS straight
+      // from the Gramian stores, PADDED to RMAX x RMAX with the identity: the factorisation runs over RMAX columns
+      // without a single `c < r` guard (r reaches this non-inlined function in a VGPR, so every guard is an
+      // exec-mask save / restore + branch around one FMA); the padding contributes exact zeros, L comes out as
+      // diag(L_r, I).
+      // (Every load is issued, from a clamped address, and the padding is selected afterwards: loads behind
+      // per-lane guards come out as one exposed round trip per entry -- 31 K cycles for 40 of them.)
+      double Lr[RMAX];
+      const int hl = lane < r ? lane : 0;
+#pragma unroll
+      for (int c = 0; c < RMAX; ++c) Lr[c] = 1.0;
+      if (a.n_modes == 3) {  // both other modes' entries in flight at once: one round trip
+        const int m1 = a.mode == 0 ? 1 : 0, m2 = a.mode == 2 ? 1 : 2;
+        const double *g1 = a.gram[m1] + hl + CALS_GLD * (long long)col, *g2 = a.gram[m2] + hl + CALS_GLD * (long long)col;
+        double t1[RMAX], t2[RMAX];
+#pragma unroll
+        for (int c = 0; c < RMAX; ++c) {
+          const long long off = CALS_GLD * (long long)(c < r ? c : 0);
+          t1[c] = g1[off];
+          t2[c] = g2[off];
+        }
+#pragma unroll
+        for (int c = 0; c < RMAX; ++c) Lr[c] = (Lr[c] * t1[c]) * t2[c];
+      } else {
+        for (int m = 0; m < a.n_modes; ++m) {
+          if (m == a.mode) continue;
+          const double *gm = a.gram[m] + hl + CALS_GLD * (long long)col;
+          double t[RMAX];
+#pragma unroll
+          for (int c = 0; c < RMAX; ++c) t[c] = gm[CALS_GLD * (long long)(c < r ? c : 0)];
+#pragma unroll
+          for (int c = 0; c < RMAX; ++c) Lr[c] *= t[c];
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < RMAX; ++c)
+        if (!(lane < r && c < r)) Lr[c] = (lane == c) ? 1.0 : 0.0;
+      UPD_STAMP(1);
+      // dpotrf('L') restated as unblocked dpotf2, RIGHT-looking: as soon as column j is final, every later column k
+      // of the row takes its term  A[i][k] -= L[i][j] L[k][j]  -- the terms of an entry arrive in the order
+      // j = 0, 1, ... with the same operands as in dpotf2's left-looking sum, but the RMAX - j - 1 updates of a
+      // column step are independent of each other.  L[k][j] comes from lane k by v_readlane (j and k are
+      // compile-time after unrolling): the factorisation touches LDS only to publish L.
+      // The pivot costs one 1/sqrt: l_jj = a * y, column = s * y with y = 1/sqrt(a) from v_rsq_f64 + two
+      // Newton steps and a final correction of l_jj.  Entries differ from IEEE sqrt / divide by at most an
+      // ulp or two -- far inside the 1e-12 the kernel tests hold against the oracle.
+      // info != 0: stop, keep going with whatever is in H, as the reference does (update.cpp:183-185 only logs):
+      // the untouched columns are published as they stand.
+      int info = 0;
+#pragma unroll
+      for (int j = 0; j < RMAX; ++j) {
+        if (info == 0) {
+          const double ajj = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(Lr[j]), j),
+                                              __builtin_amdgcn_readlane(__double2loint(Lr[j]), j));
+          if (!(ajj > 0.0)) {
+            info = j + 1;  // lane j keeps a_jj in Lr[j], as dpotf2 leaves it (only a real column can fail)
+          } else {
+#if CALS_CHOL_EXACT
+            const double ljj = sqrt(ajj);
+            const double cj = Lr[j] / ljj;
+#else
+            double y = __builtin_amdgcn_rsq(ajj);
+            y = y * fma(-0.5 * ajj * y, y, 1.5);
+            y = y * fma(-0.5 * ajj * y, y, 1.5);
+            double ljj = ajj * y;
+            ljj = fma(0.5 * y, fma(-ljj, ljj, ajj), ljj);
+            const double cj = Lr[j] * y;
+#endif
+            Lr[j] = (lane == j) ? ljj : ((lane > j) ? cj : Lr[j]);
+#pragma unroll
+            for (int k = j + 1; k < RMAX; ++k) {
+              const double lkj = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(Lr[j]), k),
+                                                  __builtin_amdgcn_readlane(__double2loint(Lr[j]), k));
+              Lr[k] -= Lr[j] * lkj;
+            }
+          }
+        }
+        if (j % PW == PW - 1) {  // a panel is complete: into LDS with it, then barrier j / PW
+#pragma unroll
+          for (int c = j - PW + 1; c <= j; ++c)
+            if (lane >= c && lane < RMAX) Hs[lane + RMAX * c] = Lr[c];
+          __syncthreads();
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      if (lane < RMAX) sh.dinv[lane] = 1.0 / Hs[lane + RMAX * lane];
+      if (lane == 0) a.mt.potrf_info[slot] = info;
+      __syncthreads();  // barrier NPAN
+      UPD_STAMP(2);
+    } else {
+      solve_row.template operator()<true>(tid - 64, tid - 64 < I);
+    }
   }
+  // the rows the pipelined pass did not take (all of them after the NNLS update): every thread
+  for (int i = solved ? tid : UPD_THREADS - 64 + tid; i < I; i += UPD_THREADS) solve_row.template operator()<false>(i, true);
   t3 = wave_sum(t3);
   if (lane == 0) sh.redt[wave] = t3;
   __syncthreads();
