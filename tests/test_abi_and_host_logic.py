@@ -4,6 +4,8 @@ include/cals_hip.h declares, fails loudly without a device, and its host-side Mu
 import ctypes
 import os
 import re
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -123,3 +125,31 @@ def test_lsap_solver_matches_scipy_and_bruteforce(oracle):
     a = np.zeros(32, dtype=np.int64)
     assert lib.cals_lsap_solve(32, big.ctypes.data_as(ctypes.c_void_p), 1, a.ctypes.data_as(ctypes.c_void_p)) == 0
     assert np.array_equal(a, linear_sum_assignment(big, maximize=True)[1])
+
+
+CRASH_CHILD = r"""
+import ctypes, os, sys
+sys.path.insert(0, {root!r})
+import cp_cals_amd
+lib = cp_cals_amd.load_library()
+evidence = os.open({evidence!r}, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
+captured = os.open({captured!r}, os.O_RDWR | os.O_CREAT | os.O_TRUNC, 0o644)
+os.dup2(captured, 2)                     # what a test runner's fd capture does to stderr
+assert lib.cals_hip_debug_install_crash_trace(evidence) == 0
+os.write(2, b"Memory access fault by GPU node-2 on address (nil)\n")   # the runtime's one line, into the capture
+os.abort()
+"""
+
+
+def test_native_abort_leaves_its_evidence_behind_a_captured_stderr(tmp_path):
+    """Round 3 lost the one line that explained an abort (a GPU memory fault) because pytest held fd 2 in a temporary
+    file when the runtime aborted.  cals_hip_debug_install_crash_trace copies the captured stderr and a native backtrace
+    to a descriptor saved before the capture; tests/conftest.py installs it for every session."""
+    ev, cap = str(tmp_path / "evidence.txt"), str(tmp_path / "captured.txt")
+    r = subprocess.run([sys.executable, "-c", CRASH_CHILD.format(root=ROOT, evidence=ev, captured=cap)],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == -6, (r.returncode, r.stderr[-2000:])  # SIGABRT still ends the process
+    text = open(ev).read()
+    assert "cals_hip crash trace: signal SIGABRT" in text
+    assert "Memory access fault by GPU node-2 on address (nil)" in text   # the captured line made it out
+    assert "backtrace of the faulting thread" in text
