@@ -707,39 +707,67 @@ static __device__ UPD_BODY_ATTR void update_body_lds(UpdArgsPtr a_ptr, int slot,
       // ulp or two -- far inside the 1e-12 the kernel tests hold against the oracle.
       // info != 0: stop, keep going with whatever is in H, as the reference does (update.cpp:183-185 only logs):
       // the untouched columns are published as they stand.
+      // Schedule (round 4): the step of column j first takes column j + 1 (the one term the next pivot waits for),
+      // starts that pivot's 1/sqrt chain -- ~150 cycles of dependent latency on a lone wave -- and applies column j to the
+      // columns behind IN THAT CHAIN'S SHADOW: one basic block, so the compiler interleaves them.  The pivot is
+      // computed speculatively and committed only if positive (a failed pivot leaves its column as dpotf2 leaves it:
+      // with every earlier column applied).  Every entry still receives its terms j = 0, 1, ... in order.
+      auto lane_val = [&](double v, int l) {
+        return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+      };
+      auto pivot = [&](double ajj, double &ljj, double &y) {  // l_jj and 1 / l_jj-ish from a_jj > 0
+#if CALS_CHOL_EXACT
+        ljj = sqrt(ajj);
+        y = 1.0 / ljj;
+#else
+        y = __builtin_amdgcn_rsq(ajj);
+        y = y * fma(-0.5 * ajj * y, y, 1.5);
+        y = y * fma(-0.5 * ajj * y, y, 1.5);
+        ljj = ajj * y;
+        ljj = fma(0.5 * y, fma(-ljj, ljj, ajj), ljj);
+#endif
+      };
       int info = 0;
+      {
+        const double a0 = lane_val(Lr[0], 0);
+        if (!(a0 > 0.0)) {
+          info = 1;  // lane j keeps a_jj in Lr[j], as dpotf2 leaves it (only a real column can fail)
+        } else {
+          double l00, y0;
+          pivot(a0, l00, y0);
+#if CALS_CHOL_EXACT
+          const double c0 = Lr[0] / l00;
+#else
+          const double c0 = Lr[0] * y0;
+#endif
+          Lr[0] = (lane == 0) ? l00 : ((lane > 0) ? c0 : Lr[0]);
+        }
+      }
 #pragma unroll
       for (int j = 0; j < RMAX; ++j) {
-        if (info == 0) {
-          const double ajj = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(Lr[j]), j),
-                                              __builtin_amdgcn_readlane(__double2loint(Lr[j]), j));
-          if (!(ajj > 0.0)) {
-            info = j + 1;  // lane j keeps a_jj in Lr[j], as dpotf2 leaves it (only a real column can fail)
-          } else {
+        if (info == 0 && j + 1 < RMAX) {  // column j is final
+          Lr[j + 1] -= Lr[j] * lane_val(Lr[j], j + 1);
+          const double an = lane_val(Lr[j + 1], j + 1);
+          const bool ok = an > 0.0;
+          double ln, yn;
+          pivot(an, ln, yn);  // (garbage when !ok: not committed)
 #if CALS_CHOL_EXACT
-            const double ljj = sqrt(ajj);
-            const double cj = Lr[j] / ljj;
+          const double cn = Lr[j + 1] / ln;
 #else
-            double y = __builtin_amdgcn_rsq(ajj);
-            y = y * fma(-0.5 * ajj * y, y, 1.5);
-            y = y * fma(-0.5 * ajj * y, y, 1.5);
-            double ljj = ajj * y;
-            ljj = fma(0.5 * y, fma(-ljj, ljj, ajj), ljj);
-            const double cj = Lr[j] * y;
+          const double cn = Lr[j + 1] * yn;
 #endif
-            Lr[j] = (lane == j) ? ljj : ((lane > j) ? cj : Lr[j]);
 #pragma unroll
-            for (int k = j + 1; k < RMAX; ++k) {
-              const double lkj = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(Lr[j]), k),
-                                                  __builtin_amdgcn_readlane(__double2loint(Lr[j]), k));
-              Lr[k] -= Lr[j] * lkj;
-            }
-          }
+          for (int k = j + 2; k < RMAX; ++k) Lr[k] -= Lr[j] * lane_val(Lr[j], k);
+          if (ok)
+            Lr[j + 1] = (lane == j + 1) ? ln : ((lane > j + 1) ? cn : Lr[j + 1]);
+          else
+            info = j + 2;
         }
-        if (j % PW == PW - 1) {  // a panel is complete: into LDS with it, then barrier j / PW
+        if (j % PW == PW - 1) {  // a panel is complete: into LDS with it (whole columns: nobody reads above the
+          if (lane < RMAX) {     // diagonal), then barrier j / PW
 #pragma unroll
-          for (int c = j - PW + 1; c <= j; ++c)
-            if (lane >= c && lane < RMAX) Hs[lane + RMAX * c] = Lr[c];
+            for (int c = j - PW + 1; c <= j; ++c) Hs[lane + RMAX * c] = Lr[c];
+          }
           __syncthreads();
         }
       }
