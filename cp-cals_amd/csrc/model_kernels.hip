@@ -808,6 +808,7 @@ static __device__ UPD_BODY_ATTR void update_body_lds(UpdArgsPtr a_ptr, int slot,
     double m = first ? 0.0 : -1.0, v = 0.0;
     if (c < r) {
       const T *xc = xs + xld * c;
+#pragma unroll 4
       for (int i = i0; i < i1; ++i) {
         const double x = (double)xc[i];
         if (first) {
