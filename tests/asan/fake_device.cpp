@@ -63,6 +63,7 @@ void enqueue(std::function<void()> f) {
     f();
 }
 // eviction schedule of a replayed pattern: the model admitted k-th leaves at iteration g_schedule[k]
+size_t g_malloc_limit = 0;  // hipMalloc refuses larger requests (0: no limit)
 std::vector<long long> g_schedule;
 size_t g_admitted = 0;
 std::map<int, long long> g_slot_target;
@@ -78,6 +79,7 @@ void fake_set_schedule(const std::vector<long long> &iters_at_eviction) {
   g_admitted = 0;
   g_slot_target.clear();
 }
+void fake_set_malloc_limit(size_t bytes) { g_malloc_limit = bytes; }
 size_t fake_queue_depth() {
   std::lock_guard<std::recursive_mutex> lock(g_mu);
   return g_queue.size();
@@ -105,6 +107,10 @@ hipError_t hipMemGetInfo(size_t *f, size_t *t) {
   return hipSuccess;
 }
 hipError_t hipMalloc(void **p, size_t n) {
+  if (g_malloc_limit && n > g_malloc_limit) {  // fake_set_malloc_limit: "the device is short of memory"
+    *p = nullptr;
+    return hipErrorOutOfMemory;
+  }
   *p = std::malloc(n ? n : 1);
   return *p ? hipSuccess : hipErrorOutOfMemory;
 }
@@ -248,7 +254,12 @@ hipError_t update_huge_factor_launch(const UpdateArgs &, int, hipStream_t) { ret
 hipError_t nnls_launch(const NnlsArgs &, hipStream_t) { return hipSuccess; }
 int nnls_rank_class(int r) { return r <= 16 ? 0 : r <= 24 ? 1 : r <= 32 ? 2 : r <= 48 ? 3 : r <= CALS_RMAX ? 4 : 5; }
 size_t nnls_huge_block_doubles() { return (size_t)CALS_GLD * CALS_GLD * 9; }
-int nnls_huge_chunks(int I, int) { return I < 16 ? 1 : (I + 15) / 16 > 16 ? 16 : (I + 15) / 16; }
+int nnls_huge_chunks(int I, int n_huge) {  // as nnls_kernel.hip: one row per wavefront (4 per workgroup) within 16 GiB
+  const size_t by_budget = ((size_t)16 << 30) / (nnls_huge_block_doubles() * sizeof(double) * (size_t)(n_huge > 0 ? n_huge : 1));
+  const int want = (I + 3) / 4;
+  const int cap = (int)(by_budget < 1 ? 1 : by_budget > 1024 ? 1024 : by_budget);
+  return want < 1 ? 1 : want < cap ? want : cap;
+}
 hipError_t nnls_reset_launch(const int *, int, const NnlsResetArgs &, hipStream_t) { return hipSuccess; }
 hipError_t reduce_partials_launch(const void *, int, int, int, int, void *, int, hipStream_t) { return hipSuccess; }
 hipError_t reduce_partials_scatter_launch(const void *, int, int, int, int, void *, const int *, int, hipStream_t) {

@@ -10,4 +10,6 @@ void fake_set_deferred(bool on);
 // (empty vector: back to the built-in pseudo-convergence rule)
 void fake_set_schedule(const std::vector<long long> &iters_at_eviction);
 size_t fake_queue_depth();
+// device allocations above this size fail with hipErrorOutOfMemory (0: no limit)
+void fake_set_malloc_limit(size_t bytes);
 #endif

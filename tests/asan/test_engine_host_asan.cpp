@@ -272,6 +272,36 @@ static void cpp_layer_driver_pattern() {
   CHECK(cp_cals(X, queue, cp).n_ktensors == 12);
 }
 
+// update::NNLS with models above rank 64 when the device cannot give the scratch nnls_huge_chunks asks for: the engine
+// halves the workgroups per model until the allocation fits instead of failing the sweep (sweep_once)
+static void nnls_scratch_under_memory_pressure() {
+  const std::vector<int64_t> modes = {40, 17, 9};
+  auto models = make_models(modes, {100, 7, 150, 90}, 31);
+  cals_hip_engine *e = nullptr;
+  CHECK(cals_hip_create(&e, 3, modes.data(), 400, 0) == CALS_HIP_OK);
+  std::vector<double> X((size_t)(40 * 17 * 9), 0.5);
+  CHECK(cals_hip_set_tensor(e, X.data()) == CALS_HIP_OK);
+  cals_hip_params p;
+  cals_hip_default_params(&p);
+  p.max_iterations = 6;
+  p.update_method = 1;
+  CHECK(cals_hip_set_params(e, &p) == CALS_HIP_OK);
+  for (auto &m : models) {
+    std::vector<double *> ptr;
+    for (auto &v : m.f) ptr.push_back(v.data());
+    CHECK(cals_hip_enqueue(e, m.rank, ptr.data(), m.lam.data(), -1, 0, &m.ticket) == CALS_HIP_OK);
+  }
+  // three models above rank 64, 10 row groups each at I = 40: 30 blocks of 4.7 MB asked for; 64 MB is all there is
+  fake_set_malloc_limit((size_t)64 << 20);
+  cals_hip_report rep;
+  const int rc = cals_hip_run(e, &rep);
+  if (rc != CALS_HIP_OK) std::printf("nnls under memory pressure: %s\n", cals_hip_last_error(e));
+  CHECK(rc == CALS_HIP_OK && rep.n_ktensors == 4);
+  fake_set_malloc_limit(0);
+  for (auto &m : models) CHECK(m.f == m.f0);
+  CHECK(cals_hip_destroy(e) == CALS_HIP_OK);
+}
+
 // The call patterns of the two round-3 anomalies, replayed on the fake device with the eviction
 // schedule of the real run (tests/asan/patterns.txt, written by tools/make_asan_patterns.py from the oracle): the
 // model admitted k-th leaves at the iteration at which the real run evicted it, so admission, eviction, compress and
@@ -381,6 +411,7 @@ int main(int argc, char **argv) {
     stepwise_api();
     n_way_group_tree();
     cpp_layer_driver_pattern();
+    nnls_scratch_under_memory_pressure();
     if (patterns) replay_patterns(patterns);
   }
   fake_set_deferred(false);
