@@ -843,6 +843,11 @@ static bool contract4_try(const E *Tb, long long S, int Mp, int M, const E *F, l
   if (passes > 4) return false;
   int gy = (int)((S / 4 + 15) / 16);
   if (gy < 1) gy = 1;
+  // small problems: as many workgroups as there are row quads (one pass per wave) while the grid stays below four rounds of 8 waves
+  // per SIMD of the whole chip -- C2 (640 columns, 100 rows): 2 -> 7 workgroups per column; C3 / C4 are unchanged.
+  // The summation of every (s, c) is the same wave-local tree: nothing changes in the results.
+  const int gy_max = (int)((S + 15) / 16);
+  while (gy < gy_max && (long long)R * (gy + 1) * 4 <= 4 * 8192) gy++;
   const dim3 grid(R, gy), block(256);
   switch (passes) {
     case 1: hipLaunchKernelGGL((contract4_kernel<E, 1>), grid, block, 0, st, Tb, S, Mp, M, F, ldF, out, ldOut); break;
