@@ -906,11 +906,20 @@ static __device__ UPD_BODY_ATTR void update_body_lds(UpdArgsPtr a_ptr, int slot,
   if (a.is_last) {
     __syncthreads();
     double t2 = 0.0;
-    for (int e = tid; e < r * r; e += UPD_THREADS) {
-      const int i = e % r, j = e / r;
-      double h = 1.0;
-      for (int m = 0; m < a.n_modes; ++m) h *= a.gram[m][i + CALS_GLD * (long long)(col + j)];
-      t2 += lams[i] * lams[j] * h;
+    // (entries of the RMAX x RMAX frame, compile-time divisions; every Gramian load of an entry issued before its use)
+    for (int e = tid; e < RMAX * RMAX; e += UPD_THREADS) {
+      const int i = e % RMAX, j = e / RMAX;
+      if (i < r && j < r) {
+        const long long at = i + CALS_GLD * (long long)(col + j);
+        double gv[CALS_MAX_MODES];
+#pragma unroll
+        for (int m = 0; m < CALS_MAX_MODES; ++m) gv[m] = (m < a.n_modes) ? a.gram[m < a.n_modes ? m : 0][at] : 1.0;
+        double h = 1.0;
+#pragma unroll
+        for (int m = 0; m < CALS_MAX_MODES; ++m)
+          if (m < a.n_modes) h *= gv[m];
+        t2 += lams[i] * lams[j] * h;
+      }
     }
     t2 = wave_sum(t2);
     __syncthreads();
