@@ -55,6 +55,9 @@ namespace calship {
 // 1: Q[s, :] fetched and read only in the stage of the last a-block of s (the one flush that consumes it) instead
 // of in every stage.  One DMA instruction and four LDS reads less per stage, but the wave-uniform branches that
 // select it cost more: measured 2.30 ms against 2.274 ms per launch at C3 -- off.
+#ifndef CALS_TTM_EARLYVM
+#define CALS_TTM_EARLYVM 0  // experiment: waves 0-3 do not wait for a flush stage's T stores at their mid-stage barrier
+#endif
 #ifndef CALS_TTM_QLAST
 #define CALS_TTM_QLAST 0
 #endif
@@ -527,7 +530,19 @@ static __device__ __forceinline__ void run(const TtmArgs &a, const int m0, const
       if constexpr (!LATE) {
         unsigned long long d0 = 0, d1 = 0, d2 = 0;
         if (DIAG(trace)) d0 = __builtin_amdgcn_s_memtime();
+#if CALS_TTM_EARLYVM
+        // A stage that flushed T (roll) issued its 4 MT stores in its first MT steps, BEHIND this wave's DMA pieces of
+        // unit iu + 1 (second half of the previous stage): the in-order counter lets the wait cover the DMA only --
+        // the stores, a microsecond old at most, need not be acknowledged before the barrier
+        if (!STRIP(512) && C::DW == 8) {
+          if (roll && 4 * MT <= 63)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"i"(4 * MT <= 63 ? 4 * MT : 0) : "memory");
+          else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+#else
         if (!STRIP(512) && C::DW == 8) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (no DMA of its own: no wait)
+#endif
         if (DIAG(trace)) d1 = __builtin_amdgcn_s_memtime();
         if (!STRIP(128)) __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
