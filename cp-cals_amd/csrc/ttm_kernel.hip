@@ -58,6 +58,9 @@ namespace calship {
 #ifndef CALS_TTM_EARLYVM
 #define CALS_TTM_EARLYVM 0  // experiment: waves 0-3 do not wait for a flush stage's T stores at their mid-stage barrier
 #endif
+#ifndef CALS_TTM_F32_STORES_BEHIND
+#define CALS_TTM_F32_STORES_BEHIND 0  // experiment (no gain, profiles/r04_ttm_f32_ladder.txt): fp32 flush stores stay outstanding across the next barrier
+#endif
 #ifndef CALS_TTM_QLAST
 #define CALS_TTM_QLAST 0
 #endif
@@ -310,7 +313,9 @@ static __device__ __forceinline__ void run(const TtmArgs &a, const int m0, const
   constexpr bool ROLL = (C::ES == 8) && (CALS_TTM_ROLL != 0);
   unsigned tvo[4];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) tvo[r] = (unsigned)((((long long)(krow + 4 * r) * S) * a.Mp + lcol) * C::ES);
+  for (int r = 0; r < 4; ++r)
+    tvo[r] = STRIP(2048) ? (unsigned)(((krow + 4 * r) * 16 + lcol) * C::ES)
+                         : (unsigned)((((long long)(krow + 4 * r) * S) * a.Mp + lcol) * C::ES);
   const char *const t_wave = reinterpret_cast<const char *>(Tout) +
                              (((long long)(nb * CALS_BN + wave * 16) * S) * a.Mp + m0) * C::ES;
   // fp32: T flush through a per-wave LDS staging tile (two tiles = 32 rows = one 128-byte line per
@@ -387,6 +392,14 @@ static __device__ __forceinline__ void run(const TtmArgs &a, const int m0, const
   int buf = 0;
   auto unit_loop = [&]<bool LATE>() {
     unsigned long long dg_vm = 0, dg_bar = 0, dg_per = 0, dg_n = 0, dg_last = 0;  // CALS_DIAG sums
+    // fp32 (round 4): the T stores of a flush cost the kernel 8.5 % (stripped build) -- not their bandwidth (0.8 TB/s) but
+    // the vmcnt(0) in front of the next barrier, which made the wave wait for their acknowledgement.  Every wave now
+    // flushes at the END of the stage (behind the DMA pieces the next barrier is about) and lets that wait cover
+    // everything BUT the NST store instructions, the youngest ones; they have a whole further stage to complete.
+    constexpr bool SB = (C::ES == 4) && (CALS_TTM_F32_STORES_BEHIND != 0) && !ROLL;
+    constexpr int NST = (MT / 2) * 2 + (MT % 2);  // store instructions of one fp32 flush
+    static_assert(NST <= 63, "vmcnt is a 6-bit counter");
+    bool flushed = false;
     bool pend = false;       // LATE: flush of the previous unit deferred behind this unit's barrier
     int s_pend = 0;
     T q_pend[C::NQ] = {};
@@ -439,7 +452,13 @@ static __device__ __forceinline__ void run(const TtmArgs &a, const int m0, const
         // BEHIND this wait, so they never sit in front of it (vmcnt counts stores too).
         unsigned long long d0 = 0, d1 = 0, d2 = 0;
         if (DIAG(trace)) d0 = __builtin_amdgcn_s_memtime();
-        if (!STRIP(512)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (!STRIP(512)) {
+          if (SB && flushed)  // the previous stage ended with a flush: its NST store instructions are the youngest
+            asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NST) : "memory");  // vector-memory operations of this wave
+          else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          flushed = false;
+        }
         if (DIAG(trace)) d1 = __builtin_amdgcn_s_memtime();
         if (!STRIP(128)) __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
@@ -489,7 +508,10 @@ static __device__ __forceinline__ void run(const TtmArgs &a, const int m0, const
       // s's values -- so during k-step 0 of a new s it still holds Q[s - 1, :].
       constexpr int QJ = MT - 1;  // the step behind whose ring read the Q reads are issued
       const bool roll = ROLL && pend;
-      const char *const t_s = t_wave + ((long long)s_pend * a.Mp) * C::ES;
+      // STRIP 2048 (timing only): every T store of the rolling flush goes to a 16-KiB window per wave that stays in L2 --
+      // the same instructions without the HBM write stream
+      const char *const t_s = STRIP(2048) ? reinterpret_cast<const char *>(Tout) + ((blockIdx.x & 255) * 8 + wave) * 16384
+                                          : t_wave + ((long long)s_pend * a.Mp) * C::ES;
       [&]<int... Is>(std::integer_sequence<int, Is...>) {
         (
             [&] {
@@ -541,7 +563,13 @@ static __device__ __forceinline__ void run(const TtmArgs &a, const int m0, const
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
 #else
-        if (!STRIP(512) && C::DW == 8) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (no DMA of its own: no wait)
+        if (!STRIP(512) && C::DW == 8) {  // (no DMA of its own: no wait)
+          if (SB && flushed)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NST) : "memory");
+          else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          flushed = false;
+        }
 #endif
         if (DIAG(trace)) d1 = __builtin_amdgcn_s_memtime();
         if (!STRIP(128)) __builtin_amdgcn_s_barrier();
@@ -586,7 +614,7 @@ static __device__ __forceinline__ void run(const TtmArgs &a, const int m0, const
 
       if constexpr (ROLL) pend = false;
       if (ab_c == nAb - 1) {
-        if constexpr (LATE || ROLL) {
+        if constexpr (ROLL || (LATE && !SB)) {
           pend = true;
           s_pend = s_c;
           if constexpr (!ROLL) {
@@ -595,6 +623,7 @@ static __device__ __forceinline__ void run(const TtmArgs &a, const int m0, const
           }
         } else {
           flush(s_c, qcur);
+          flushed = true;
         }
       }
       buf = (buf == 2) ? 0 : buf + 1;
