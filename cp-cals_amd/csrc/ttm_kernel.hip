@@ -329,7 +329,8 @@ static __device__ __forceinline__ void run(const TtmArgs &a, const int m0, const
     const int c8 = (lane >> 3) + 8 * h;
     const int gc = nb * CALS_BN + wave * 16 + c8;
     tv[h] = st;
-    tb[h] = Tout + ((long long)gc * S) * a.Mp + m0 + 4 * j8;
+    tb[h] = STRIP(2048) ? Tout + ((blockIdx.x & 255) * 8 + wave) * 4096 + c8 * 64 + 4 * j8  // (timing only: an L2-resident window)
+                        : Tout + ((long long)gc * S) * a.Mp + m0 + 4 * j8;
   }
   // fp32, odd MT: the last tile alone (16 rows = 64 B per column, 4 lanes per column)
   const int gc4 = nb * CALS_BN + wave * 16 + (lane >> 2);
@@ -340,7 +341,7 @@ static __device__ __forceinline__ void run(const TtmArgs &a, const int m0, const
   // contraction); T = 0
   auto flush = [&](int s, const T (&qv)[C::NQ]) {
     asm volatile("" ::: "memory");
-    const long long so = (long long)s * a.Mp;
+    const long long so = STRIP(2048) ? 0 : (long long)s * a.Mp;
     if constexpr (C::ES == 8) {
 #pragma unroll
       for (int t = 0; t < MT; ++t) {
