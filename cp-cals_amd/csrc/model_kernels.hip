@@ -1454,9 +1454,18 @@ __global__ void __launch_bounds__(UPD_THREADS, 2) update_lds_kernel(const Update
   // {slot, first column, rank, jackknife (mode, fiber) packed} of this workgroup's model in ONE load (UpdateArgs::
   // wgdesc, written by the engine with the slot list): slot -> rank -> column were three dependent round trips in
   // front of the first Gramian load
+#ifdef CALS_DIAG
+  const unsigned long long t_entry = __builtin_amdgcn_s_memtime();
+#endif
   const int4 d = a.wgdesc[blockIdx.x];
   const int slot = d.x, col = d.y, r = d.z, jkp = d.w;
   if (r > CALS_RFAST) return;
+#ifdef CALS_DIAG  // kernel entry and "descriptor arrived" next to the body's phase stamps (tools/update_trace.py)
+  if (a.dbg_trace && a.mode == 0 && r == 20 && blockIdx.x < 24 && threadIdx.x == 0) {
+    a.dbg_trace[8] = t_entry;
+    a.dbg_trace[9] = __builtin_amdgcn_s_memtime();
+  }
+#endif
   UPD_DISPATCH(update_body_lds);
 }
 

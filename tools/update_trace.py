@@ -19,9 +19,9 @@ for modes, nm in (([100, 100, 100], 64), ([300, 300, 300], 256)):
     e.sweep(3); e.synchronize()
     buf = (C.c_uint64 * (16 * 2048))()
     e._chk(e.lib.cals_hip_debug_ttm_trace(e.h, buf, 16 * 2048))
-    t = np.frombuffer(buf, dtype=np.uint64).astype(np.int64)[16 * 2048 - 64:][:8]
+    t = np.frombuffer(buf, dtype=np.uint64).astype(np.int64)[16 * 2048 - 64:][:10]
     # update_body_lds stamps 0 1 2 3 5 6 7 (no stamp 4: the column scales and lambda are one phase there)
     names = ["hadamard", "cholesky", "rows: solve", "col stats + lambda", "scale pass", "pt + gramian"]
     tt = t[[0, 1, 2, 3, 5, 6, 7]]
-    print(modes, "update_kernel phases (cycles @2.39 GHz):", ", ".join("%s %d" % (n, d) for n, d in zip(names, np.diff(tt))), "| total", t[7] - t[0])
+    print(modes, "update_kernel phases (cycles @2.39 GHz):", ", ".join("%s %d" % (n, d) for n, d in zip(names, np.diff(tt))), "| total", t[7] - t[0], "| kernel entry -> descriptor %d -> body start %d" % (t[9] - t[8], t[0] - t[9]))
     e.close()
