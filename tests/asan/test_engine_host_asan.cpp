@@ -404,7 +404,8 @@ static void replay_patterns(const char *path) {
 int main(int argc, char **argv) {
   const char *patterns = argc > 1 ? argv[1] : nullptr;
   // twice: a device that completes everything at once, then one that is as late as the API allows (fake_device.cpp)
-  for (int deferred = 0; deferred < 2; deferred++) {
+  // (CALS_HARNESS_ONLY_LATE=1: the late schedule only -- the ThreadSanitizer run, which is about the two host threads)
+  for (int deferred = std::getenv("CALS_HARNESS_ONLY_LATE") ? 1 : 0; deferred < 2; deferred++) {
     fake_set_deferred(deferred != 0);
     c_abi_life_cycles(CALS_HIP_F64);
     c_abi_life_cycles(CALS_HIP_F32);

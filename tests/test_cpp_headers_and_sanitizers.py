@@ -146,7 +146,7 @@ def test_engine_host_side_under_thread_sanitizer():
     that claim models from one queue through a shared atomic counter (cals/cals.cpp: cp_cals_devices)."""
     exe = os.path.join(ROOT, "tests", "asan", "test_engine_host_tsan")
     assert os.path.exists(exe), "run __graft_entry__.build() first"
-    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=1:second_deadlock_stack=1")
+    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=1:second_deadlock_stack=1", CALS_HARNESS_ONLY_LATE="1")
     # (ASLR off for the child: this kernel's 32-bit mmap entropy trips older TSan runtimes, "unexpected memory mapping")
     cmd = [exe, os.path.join(ROOT, "tests", "asan", "patterns.txt")]
     if os.path.exists("/usr/bin/setarch"):
