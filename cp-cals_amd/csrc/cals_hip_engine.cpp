@@ -199,6 +199,13 @@ struct cals_hip_engine {
   StatusRec *d_status = nullptr, *h_status = nullptr;
   size_t status_cap = 0;
   bool changed_deferred = false;  // run(): the line-search "changed" flag travels with the status
+  // Line-search-aware pair schedule (plan M): when every model extrapolates in the same sweep (models admitted
+  // together keep one phase: bench config 3) the T handed over that sweep's boundary is always lost.  Two such
+  // events one line-search interval apart predict the next one; in the predicted sweep the last mode runs the plain
+  // fused MTTKRP instead of a TTM whose T nobody would consume (the same G, no 1.9 GB of T written).
+  int64_t ls_sweep_no = 0;                       // sweeps with line search on, counted by sweep_once
+  int64_t ls_event_at[2] = {-1, -1};             // sweep numbers of the last two mass extrapolations
+  bool ls_event_predicted = false;               // the sweep in progress is predicted to end with one
   std::vector<int> h_flags;
   std::vector<long long> h_iters;
   std::vector<double> h_err, h_fit, h_old_fit;
@@ -891,13 +898,29 @@ void pt_invalidate(cals_hip_engine *e) { e->tree.pt_mode = -1; }
 // mode runs a fresh TTM -- which costs about what patching more than half of the columns would, and
 // leaves a T for the mode after it.
 void note_ls_changes(cals_hip_engine *e, int changed) {
-  if (changed <= 0 || e->tree.t_second < 0) return;
   const char *env = getenv("CALS_TREE_PATCH_MAX");  // tests: 0 = always drop, 1 = always patch
   const double keep_below = env ? atof(env) : 0.5;
+  const bool mass = e->prm.line_search_method == 0 && (double)changed > keep_below * (double)e->end;
+  if (mass) {  // (ls_sweep_no was advanced by the sweep this belongs to)
+    e->ls_event_at[0] = e->ls_event_at[1];
+    e->ls_event_at[1] = e->ls_sweep_no;
+  } else if (e->ls_event_predicted) {
+    e->ls_event_at[0] = e->ls_event_at[1] = -1;  // predicted, did not happen: forget the pattern
+  }
+  e->ls_event_predicted = false;
+  if (changed <= 0 || e->tree.t_second < 0) return;
   if (e->prm.line_search_method == 0 && (double)changed <= keep_below * (double)e->end)
     e->tree.n_stale = changed;
   else
     tree_invalidate(e);
+}
+
+// the sweep about to run is predicted to end with a mass extrapolation (see cals_hip_engine::ls_event_at)
+bool ls_event_due(const cals_hip_engine *e) {
+  const bool off = getenv("CALS_LS_SCHEDULE_OFF") != nullptr;  // A/B switch (read every sweep: tests flip it)
+  if (off || !e->prm.line_search || e->prm.line_search_method != 0) return false;
+  const int64_t period = e->ls_event_at[1] - e->ls_event_at[0];
+  return e->ls_event_at[0] >= 0 && period == e->prm.line_search_interval && e->ls_sweep_no + 1 == e->ls_event_at[1] + period;
 }
 
 int ensure_col_scratch(cals_hip_engine *e, size_t words, size_t n_idx);
@@ -990,6 +1013,8 @@ int sweep_once(cals_hip_engine *e, bool evict_enabled, bool defer_changed = fals
     const int pk = prof_begin(e, 2, 0, LOG_LS);
     HIPCHK(ls_snapshot_launch(la, e->stream));
     prof_end(e, pk);
+    e->ls_event_predicted = e->tree.kind == 3 && ls_event_due(e);
+    e->ls_sweep_no++;
   }
   int rank_max = 1;  // sizes the update kernel's LDS panel
   size_t n_huge = 0;  // models above CALS_RMAX: nnls_huge_kernel / the EC line search need global H / L blocks for them
@@ -1125,7 +1150,8 @@ int sweep_once(cals_hip_engine *e, bool evict_enabled, bool defer_changed = fals
       if (e->tree.n_stale > 0 && (rc = patch_stale_columns(e, n))) return rc;
       tree_invalidate(e);  // T is consumed: mode a of the pair is updated next
     } else if (e->tree.on && e->tree.pair[n].on &&
-               !(e->tree.kind == 3 && n == e->n_modes - 1 && evict_enabled && !e->queue.empty())) {
+               !(e->tree.kind == 3 && n == e->n_modes - 1 &&
+                 ((evict_enabled && !e->queue.empty()) || (e->prm.line_search && e->ls_event_predicted)))) {
       // (Plan M's last pair hands its T over the sweep boundary.  While models are waiting in the
       // queue the column layout changes after nearly every sweep -- eviction, compress, admission --
       // and that T would be dropped unused: the plain fused MTTKRP is the cheaper way to G then.)
@@ -1221,7 +1247,8 @@ int sweep_once(cals_hip_engine *e, bool evict_enabled, bool defer_changed = fals
   if (e->prm.line_search) {
     LsArgs la = make_ls_args(e);
     const int pk = prof_begin(e, 2, 0, LOG_LS);
-    const bool pending = e->tree.t_second >= 0;  // a T shared across the sweep boundary
+    // a T shared across the sweep boundary -- or none BECAUSE a mass extrapolation was predicted: the count confirms it
+    const bool pending = e->tree.t_second >= 0 || e->ls_event_predicted;
     pt_invalidate(e);  // the line-search kernels may rewrite any model's factors
     if (pending) HIPCHK(hipMemsetAsync(e->tree.d_changed, 0, sizeof(int), e->stream));
     la.changed = pending ? e->tree.d_changed : nullptr;
@@ -2038,6 +2065,9 @@ int cals_hip_rebind(cals_hip_engine *e, int64_t buffer_size) {
   e->slots_dirty = true;
   e->n_ktensors = e->comp_sum = e->ls_performed = e->ls_failed = 0;
   e->changed_deferred = false;
+  e->ls_sweep_no = 0;
+  e->ls_event_at[0] = e->ls_event_at[1] = -1;
+  e->ls_event_predicted = false;
   // a binding is a fresh run: nothing of the previous one may show up in its report (cals_hip_get_report's
   // iter = sweeps, the sticky NNLS status word) or in its sweep log
   e->sweeps = 0;

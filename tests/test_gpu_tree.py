@@ -121,9 +121,12 @@ def test_plan_m_keeps_a_pending_T_across_line_search(cc, oracle, inputs, patch_m
     ranks = inputs.ranks_1_to_20(23) + [7, 3]      # R = 233: two column blocks, the second partly filled
     X = inputs.low_rank_tensor(modes, 5, seed=13)[0] + 0.3 * inputs.tensor(modes, 9)
     iters = 23
-    old = {k: os.environ.get(k) for k in ("CALS_HIP_TREE", "CALS_TREE_PATCH_MAX")}
+    old = {k: os.environ.get(k) for k in ("CALS_HIP_TREE", "CALS_TREE_PATCH_MAX", "CALS_LS_SCHEDULE_OFF")}
     os.environ["CALS_HIP_TREE"] = "M"
     os.environ["CALS_TREE_PATCH_MAX"] = patch_max
+    # (the launch counts below are about patching: the line-search-aware pair schedule, which replaces a TTM by a fused
+    # MTTKRP in a sweep predicted to end with a mass extrapolation, has its own test right below)
+    os.environ["CALS_LS_SCHEDULE_OFF"] = "1"
     try:
         base = make_models(inputs, modes, ranks, seed=2)
         e = cc.Engine(modes, sum(ranks), dtype=dtype)
@@ -161,6 +164,61 @@ def test_plan_m_keeps_a_pending_T_across_line_search(cc, oracle, inputs, patch_m
         assert ks.mttkrp_launches == 0
     else:
         assert ks_mid.mttkrp_launches > 0 and ks.mttkrp_launches > ks_mid.mttkrp_launches
+
+
+def test_line_search_aware_pair_schedule(cc, oracle, inputs):
+    """Plan M, models admitted together: every model extrapolates in the same sweep, every `interval` sweeps, and the T
+    handed over that sweep's boundary is always lost.  After two such events the engine predicts the next one and runs
+    the plain fused MTTKRP at that sweep's last mode instead of a TTM nobody would consume: same models as the oracle,
+    fewer TTM launches, one fused launch per predicted event -- and exactly the models of the unscheduled run up to the
+    association of the sums."""
+    # (an ODD interval: with an even one the events fall on sweeps that hand no T over, and there is nothing to save;
+    # the data of test_tree_line_search_vs_oracle: far from convergence, so no accept / revert decision is a near-tie
+    # that the different association of one MTTKRP's sums could flip)
+    modes, ranks, iters, interval = [20, 20, 20], [2, 3, 4, 5, 20, 17], 25, 5
+    X = inputs.tensor(modes, 3)
+    base = make_models(inputs, modes, ranks, seed=5)
+    old = {k: os.environ.get(k) for k in ("CALS_HIP_TREE", "CALS_LS_SCHEDULE_OFF")}
+    os.environ["CALS_HIP_TREE"] = "M"
+    out = {}
+    try:
+        for off in (True, False):
+            if off:
+                os.environ["CALS_LS_SCHEDULE_OFF"] = "1"
+            else:
+                os.environ.pop("CALS_LS_SCHEDULE_OFF", None)
+            e = cc.Engine(modes, sum(ranks))
+            e.set_tensor(X)
+            e.set_params(cc.default_params(max_iterations=iters, force_max_iter=1, line_search=1,
+                                           line_search_interval=interval))
+            gm = [cc.Model([f.copy() for f in fs], lam.copy()) for fs, lam, _ in base]
+            for m in gm:
+                e.enqueue(m)
+            e.set_profiling(1)
+            rep = e.run()
+            ks = e.kernel_stats()
+            e.close()
+            out[off] = (gm, ks.ttm_launches, ks.mttkrp_launches, rep.iter)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    (g_off, ttm_off, fused_off, it_off), (g_on, ttm_on, fused_on, it_on) = out[True], out[False]
+    # The first two mass extrapolations teach the period, later ones are predicted -- as long as the models stay in
+    # phase (a model whose step is reverted falls one sweep behind).  Every correct prediction turns one TTM into one
+    # fused launch; a wrong one costs an extra GEMM and clears the pattern.
+    # (Fused launches also serve the stale-column patch, with or without the schedule: only the TTM count is telling.)
+    assert it_on == it_off
+    assert ttm_on < ttm_off and fused_on > 0
+    om = [oracle.Model([f.copy() for f in fs], lam.copy()) for fs, lam, _ in base]
+    oracle.cp_cals(X, modes, om, oracle.default_params(max_iterations=iters, force_max_iter=1, buffer_size=sum(ranks),
+                                                       mttkrp_method=oracle.MTTKRP, line_search=1,
+                                                       line_search_interval=interval))
+    for a, b, c in zip(g_on, g_off, om):
+        for fa, fb, fc in zip(a.factors, b.factors, c.factors):
+            assert rel(fa, fb) < 1e-9 and rel(fa, fc) < 1e-8
 
 
 def test_tree_error_checking_line_search_vs_oracle(cc, oracle, inputs, plan):
