@@ -41,7 +41,8 @@ namespace calship {
 #endif
 // Timing-only stripping, compile time (results garbage; tools/ttm_strip.sh builds the variants): bit 1 no T stores,
 // 8 no P DMA, 16 no X DMA, 32 no flush FMAs, 64 no Q reads, 128 no stage barrier, 256 P operands read once,
-// 512 no vmcnt wait in front of the barrier.  (A probe that ADDED a plain 16-byte-per-lane register
+// 512 no vmcnt wait in front of the barrier, 4096 fp32 flush without the LDS round trip, 8192 only half the tiles stored,
+// 16384 T stores carry half (fp64) / a quarter (fp32) of their bytes.  (A probe that ADDED a plain 16-byte-per-lane register
 // load per P piece showed that any vector-memory instruction costs what an LDS-DMA piece costs, profiles/r03_ttm_strip_ladder.txt.)  (The run-time CALS_TTM_DBG bits of CALS_DIAG builds cost registers:
 // the DIAG kernel spills and runs at half speed -- useless for this.)
 #ifndef CALS_TTM_STRIP
@@ -355,6 +356,16 @@ static __device__ __forceinline__ void run(const TtmArgs &a, const int m0, const
     } else {
 #pragma unroll
       for (int t = 0; t + 1 < MT; t += 2) {
+        if constexpr (STRIP(4096)) {  // timing only: the same 16-byte stores straight from the registers (wrong places), no LDS round trip
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) gacc[t + k][r] += tacc[t + k][r] * qv[0];
+            if (tv[k]) __builtin_nontemporal_store(tacc[t + k], reinterpret_cast<acc_t *>(tb[k] + so + 16 * t));
+            tacc[t + k] = (acc_t){0, 0, 0, 0};
+          }
+          continue;
+        }
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
 #pragma unroll
@@ -365,7 +376,12 @@ static __device__ __forceinline__ void run(const TtmArgs &a, const int m0, const
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           const acc_t v = *reinterpret_cast<const acc_t *>(stg + ((lane >> 3) + 8 * h) * C::SP + 4 * j8);
-          if (tv[h]) __builtin_nontemporal_store(v, reinterpret_cast<acc_t *>(tb[h] + so + 16 * t));
+          if (tv[h] && !(STRIP(8192) && t >= MT / 2)) {
+            if constexpr (STRIP(16384))  // timing only: the same store instructions carrying a quarter of the bytes
+              __builtin_nontemporal_store(v[0], tb[h] + so + 16 * t);
+            else
+              __builtin_nontemporal_store(v, reinterpret_cast<acc_t *>(tb[h] + so + 16 * t));
+          }
         }
       }
       if constexpr (MT % 2 == 1) {
@@ -521,9 +537,14 @@ static __device__ __forceinline__ void run(const TtmArgs &a, const int m0, const
 #pragma unroll
                   for (int r = 0; r < 4; ++r) {
                     if (!STRIP(32)) gacc[Is][r] += tacc[Is][r] * q_pend[r];
-                    if (st)
-                      asm volatile("global_store_dwordx2 %0, %1, %2 offset:%3 nt"
-                                   :: "v"(tvo[r]), "v"(tacc[Is][r]), "s"(t_s), "i"(16 * Is * C::ES) : "memory");
+                    if (st && !(STRIP(8192) && Is >= MT / 2)) {
+                      if constexpr (STRIP(16384))  // timing only: the same store instructions carrying half the bytes
+                        asm volatile("global_store_dword %0, %1, %2 offset:%3 nt"
+                                     :: "v"(tvo[r]), "v"((float)tacc[Is][r]), "s"(t_s), "i"(16 * Is * C::ES) : "memory");
+                      else
+                        asm volatile("global_store_dwordx2 %0, %1, %2 offset:%3 nt"
+                                     :: "v"(tvo[r]), "v"(tacc[Is][r]), "s"(t_s), "i"(16 * Is * C::ES) : "memory");
+                    }
                   }
                   // (the MFMA's inline constant C = 0 would save these four moves, but as inline asm with the tile
                   // tied in place the allocator copies tiles through a second register set: 130 spills at MT 10)
