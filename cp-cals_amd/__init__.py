@@ -81,7 +81,7 @@ EXPORTS = [
     "cals_hip_reset_kernel_stats", "cals_hip_stream", "cals_hip_device_count",
     "cals_hip_create_ex", "cals_hip_dtype", "cals_hip_tree", "cals_hip_set_tensor_f32",
     "cals_hip_rebind", "cals_hip_capacity", "cals_hip_set_sweep_log", "cals_hip_get_sweep_log",
-    "cals_hip_debug_clock", "cals_hip_debug_ttm_trace", "cals_hip_debug_install_crash_trace", "cals_hip_host_first_fit", "cals_hip_host_compress_plan", "cals_hip_host_active_cols",
+    "cals_hip_debug_clock", "cals_hip_debug_ttm_trace", "cals_hip_debug_ls_margin", "cals_hip_debug_install_crash_trace", "cals_hip_host_first_fit", "cals_hip_host_compress_plan", "cals_hip_host_active_cols",
 ]
 
 _LIB = None
@@ -137,6 +137,7 @@ def load_library():
     lib.cals_hip_debug_get_gramian.argtypes = [vp, C.c_int, dp]
     lib.cals_hip_debug_model_status.argtypes = [vp, i64, C.POINTER(ModelStatus), C.POINTER(i64)]
     lib.cals_hip_debug_get_norms.argtypes = [vp, dp, dp]
+    lib.cals_hip_debug_ls_margin.argtypes = [vp, i64, dp]
     lib.cals_hip_set_profiling.argtypes = [vp, C.c_int]
     lib.cals_hip_get_kernel_stats.argtypes = [vp, C.POINTER(KernelStats)]
     lib.cals_hip_reset_kernel_stats.argtypes = [vp]
@@ -383,6 +384,13 @@ class Engine:
         col = C.c_int64(-1)
         self._chk(self.lib.cals_hip_debug_model_status(self.h, model.ticket, C.byref(st), C.byref(col)))
         return st, col.value
+
+    def ls_margin(self, model):
+        """cals_hip_debug_ls_margin: the smallest relative distance between the two errors of any accept / revert test
+        the model went through (1e300: none).  Rounding-level = the decision was a tie."""
+        m = C.c_double(0)
+        self._chk(self.lib.cals_hip_debug_ls_margin(self.h, model.ticket, C.byref(m)))
+        return m.value
 
     def debug_norms(self):
         xn = C.c_double(0)

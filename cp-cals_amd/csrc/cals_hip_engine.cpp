@@ -42,6 +42,7 @@ struct HostModel {
   int64_t id = 0;  // MultiKtensor unique_kt_id
   int ls_iter = 0;  // host mirror of LineSearchParams::iter for the error-checking methods
   cals_hip_model_status st{};
+  double ls_margin = 1e300;  // ModelTable::ls_margin at eviction
 };
 
 struct ModeLayout {
@@ -208,7 +209,7 @@ struct cals_hip_engine {
   bool ls_event_predicted = false;               // the sweep in progress is predicted to end with one
   std::vector<int> h_flags;
   std::vector<long long> h_iters;
-  std::vector<double> h_err, h_fit, h_old_fit;
+  std::vector<double> h_err, h_fit, h_old_fit, h_ls_margin;
 
   std::vector<HostModel> models;   // by ticket
   std::deque<int64_t> queue;       // tickets
@@ -1344,6 +1345,7 @@ int fetch_status(cals_hip_engine *e) {
     e->h_err[slot] = r.err;
     e->h_fit[slot] = r.fit;
     e->h_old_fit[slot] = r.old_fit;
+    e->h_ls_margin[slot] = r.ls_margin;
   }
   return CALS_HIP_OK;
 }
@@ -1468,6 +1470,7 @@ int remove_models(cals_hip_engine *e, std::vector<int64_t> rm) {
     m.st.approx_error = e->h_err[m.slot];
     m.st.fit = e->h_fit[m.slot];
     m.st.old_fit = e->h_old_fit[m.slot];
+    m.ls_margin = e->h_ls_margin[m.slot];
     m.state = 2;  // st.evicted is set once the factors have landed in the caller's storage
     for (int64_t c = m.col; c < m.col + m.rank; c++) e->occ[(size_t)c] = 0;
     e->free_slots.push_back(m.slot);
@@ -2021,6 +2024,7 @@ int cals_hip_create_ex(cals_hip_engine **out, int n_modes, const int64_t *modes,
   if ((rc = dev_alloc(e, &e->mt.bk_old_fit, ms))) return rc;
   if ((rc = dev_alloc(e, &e->mt.bk_iters, ms))) return rc;
   if ((rc = dev_alloc(e, &e->mt.flags, ms))) return rc;
+  if ((rc = dev_alloc(e, &e->mt.ls_margin, ms))) return rc;
   if ((rc = dev_alloc(e, &e->d_slots, ms))) return rc;
   if ((rc = dev_alloc(e, &e->d_wgdesc, ms))) return rc;
   if ((rc = dev_alloc(e, &e->d_cls_idx, ms))) return rc;
@@ -2030,6 +2034,7 @@ int cals_hip_create_ex(cals_hip_engine **out, int n_modes, const int64_t *modes,
   e->h_err.assign(ms, 0.0);
   e->h_fit.assign(ms, 0.0);
   e->h_old_fit.assign(ms, 0.0);
+  e->h_ls_margin.assign(ms, 1e300);
   for (int s = e->max_slots - 1; s >= 0; s--) e->free_slots.push_back(s);
   e->occ.assign((size_t)buffer_size, 0);
   adjust_edges(e);
@@ -2185,6 +2190,7 @@ int cals_hip_destroy(cals_hip_engine *e) {
   fr(e->mt.bk_old_fit);
   fr(e->mt.bk_iters);
   fr(e->mt.flags);
+  fr(e->mt.ls_margin);
   fr(e->d_slots);
   fr(e->d_wgdesc);
   fr(e->d_cls_idx);
@@ -2729,6 +2735,20 @@ int cals_hip_debug_model_status(cals_hip_engine *e, int64_t ticket, cals_hip_mod
   st->old_fit = e->h_old_fit[m.slot];
   st->evicted = 0;
   if (col) *col = m.col;
+  return CALS_HIP_OK;
+}
+
+int cals_hip_debug_ls_margin(cals_hip_engine *e, int64_t ticket, double *margin) {
+  if (!e || !margin || ticket < 0 || ticket >= (int64_t)e->models.size()) return CALS_HIP_ERR_ARG;
+  HIPCHK(hipSetDevice(e->device));
+  const HostModel &m = e->models[(size_t)ticket];
+  if (m.state == 1) {
+    int rc = fetch_status(e);
+    if (rc) return rc;
+    *margin = e->h_ls_margin[m.slot];
+  } else {
+    *margin = m.ls_margin;
+  }
   return CALS_HIP_OK;
 }
 

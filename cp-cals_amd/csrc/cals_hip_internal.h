@@ -133,6 +133,10 @@ struct ModelTable {
   double *bk_err, *bk_fit, *bk_old_fit;  // backup_ktensor scalars
   long long *bk_iters;
   int *flags;          // bit0: extrapolated this sweep, bit1: reversed this sweep, bit2: evict
+  // smallest relative distance |e1 - e2| / max(|e1|, |e2|) between the two errors of any accept / revert test this
+  // model has been through (line_search.cpp:239 / :116): a test whose margin is at rounding level is a tie, and
+  // either outcome is a valid trajectory (cals_hip_debug_ls_margin; the tests that allow a flipped decision check it)
+  double *ls_margin;
 };
 
 // smallest rank whose unconstrained update runs as the pipeline of huge_* launches (33 | 49 | 65; measured)
@@ -331,6 +335,7 @@ struct StatusRec {
   int flags, pad;      // pad = slot (header record: flags = line-search "changed" flag, pad = NNLS status)
   long long iters;     // header record: number of records that follow
   double err, fit, old_fit;
+  double ls_margin;    // ModelTable::ls_margin
 };
 // nnls_status (may be null) lands in the header record's `pad`
 hipError_t pack_status_launch(const int *slots, int n, const ModelTable &mt, const int *changed,

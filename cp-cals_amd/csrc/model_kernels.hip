@@ -2177,6 +2177,7 @@ __global__ void init_slots_kernel(const int *desc, int n, ModelTable mt) {
   mt.ls_iter[slot] = 0;
   mt.ls_updated_last[slot] = 0;
   mt.flags[slot] = 0;
+  mt.ls_margin[slot] = 1e300;
 }
 
 hipError_t init_slots_launch(const int *desc, int n, const ModelTable &mt, hipStream_t st) {
@@ -2414,6 +2415,13 @@ __global__ void __launch_bounds__(256) ls_snapshot_kernel(const LsArgs a) {
   if (threadIdx.x < r) a.prev_lambda[col + threadIdx.x] = a.lambda[col + threadIdx.x];
 }
 
+// ModelTable::ls_margin: how far from a tie the accept / revert test of errors e1, e2 was
+__device__ __forceinline__ void ls_note_margin(const ModelTable &mt, int slot, double e1, double e2) {
+  const double scale = fmax(fmax(fabs(e1), fabs(e2)), 1e-300);
+  const double m = fabs(e1 - e2) / scale;
+  if (!(m >= mt.ls_margin[slot])) mt.ls_margin[slot] = m;  // NaN errors read as a tie
+}
+
 // ls::line_search (src/utils/line_search.cpp:228-271) for every model, after the error update.
 template <typename T>
 __global__ void __launch_bounds__(256) ls_kernel(const LsArgs a) {
@@ -2430,6 +2438,7 @@ __global__ void __launch_bounds__(256) ls_kernel(const LsArgs a) {
   const double step = (a.step == 0.0) ? cbrt((double)iters) : a.step;
   bool regram = false;
   if (a.mt.ls_updated_last[slot]) {
+    if (tid == 0) ls_note_margin(a.mt, slot, a.mt.bk_err[slot], a.mt.err[slot]);
     if (a.mt.bk_err[slot] < a.mt.err[slot]) {
       // revert to the backup (Ktensor::copy, src/ktensor.cpp:163-181: scalars, lambda, factors)
       flags |= 2;
@@ -2668,7 +2677,10 @@ __global__ void __launch_bounds__(256) ls_ec_decide_kernel(const LsArgs a) {
   t3 = red[0] + red[1] + red[2] + red[3];
   // the reference evaluates the candidate against the FULL tensor, jackknife models included
   const double error = sqrt(fmax(a.X_norm * a.X_norm + t2 - 2.0 * t3, 0.0));
-  if (tid == 0) s_accept = (error < a.mt.err[slot]) ? 1 : 0;
+  if (tid == 0) {
+    ls_note_margin(a.mt, slot, error, a.mt.err[slot]);
+    s_accept = (error < a.mt.err[slot]) ? 1 : 0;
+  }
   __syncthreads();
   if (!s_accept) {
     if (tid == 0) a.mt.flags[slot] = 3;  // extrapolated + reversed
@@ -2783,6 +2795,7 @@ __global__ void pack_status_kernel(const int *slots, int n, ModelTable mt, const
     h.pad = nnls_status ? *nnls_status : 0;
     h.iters = n;
     h.err = h.fit = h.old_fit = 0.0;
+    h.ls_margin = 0.0;
     out[0] = h;
   }
   if (k >= n) return;
@@ -2794,6 +2807,7 @@ __global__ void pack_status_kernel(const int *slots, int n, ModelTable mt, const
   r.err = mt.err[slot];
   r.fit = mt.fit[slot];
   r.old_fit = mt.old_fit[slot];
+  r.ls_margin = mt.ls_margin[slot];
   out[1 + k] = r;
 }
 

@@ -247,6 +247,13 @@ int cals_hip_debug_model_status(cals_hip_engine *e, int64_t ticket, cals_hip_mod
                                 int64_t *col);
 /* jackknife norms / X norm computed on the device at set_tensor */
 int cals_hip_debug_get_norms(cals_hip_engine *e, double *X_norm, double *jk_norms /* modes[0] or NULL */);
+/* How close to a tie the model's line-search decisions were: the smallest |e1 - e2| / max(|e1|, |e2|) over every
+ * accept / revert test the model has been through (ls::line_search's `backup error < error`,
+ * src/utils/line_search.cpp:239; the error-checking methods' `new error < old error`, :116); 1e300 when it has been
+ * through none.  A converged model's extrapolation is a null step and its test compares two errors that agree to
+ * rounding: either outcome is then a valid trajectory of the reference's algorithm.  The tests that tolerate a
+ * flipped decision use this to show that every flipped one WAS such a tie.  No counterpart in the reference. */
+int cals_hip_debug_ls_margin(cals_hip_engine *e, int64_t ticket, double *margin);
 
 /* ---- host logic of MultiKtensor, exposed so that it can be tested without a GPU ---- */
 /* MultiKtensor::check_availability (src/multi_ktensor.cpp:14-39) on an occupancy vector (id per

@@ -676,6 +676,9 @@ typedef struct {
   int normalized;
   int jk, jk_mode;
   int64_t jk_fiber;
+  /* test instrumentation, no counterpart in the reference: how close to a tie the accept / revert tests of the line
+   * search were for this Ktensor (or_model::ls_margin); not part of Ktensor::copy */
+  double ls_margin;
 } kt_t;
 
 static void kt_alloc(kt_t *k, int64_t rank, int n_modes, const int64_t *modes) {
@@ -718,6 +721,7 @@ static void kt_from_model(kt_t *k, or_model *m, int n_modes, const int64_t *mode
   k->jk = m->jk_enabled;
   k->jk_mode = m->jk_mode;
   k->jk_fiber = m->jk_fiber;
+  k->ls_margin = 1e300;
 }
 
 static void kt_to_model(const kt_t *k, or_model *m) {
@@ -725,6 +729,7 @@ static void kt_to_model(const kt_t *k, or_model *m) {
   m->fit = k->fit;
   m->old_fit = k->old_fit;
   m->approx_error = k->err;
+  m->ls_margin = k->ls_margin;
 }
 
 /* Ktensor::copy, src/ktensor.cpp:163-181 (id and jk are NOT copied) */
@@ -812,6 +817,13 @@ static void ls_no_error_checking(kt_t *k, kt_t *prev, double *const *gram, ls_t 
   update_gramians(k, gram);
 }
 
+/* or_model::ls_margin: smallest |e1 - e2| / max(|e1|, |e2|) over the tests so far (NaN reads as a tie) */
+static void ls_note_margin(kt_t *k, double e1, double e2) {
+  const double scale = fmax(fmax(fabs(e1), fabs(e2)), 1e-300);
+  const double m = fabs(e1 - e2) / scale;
+  if (!(m >= k->ls_margin)) k->ls_margin = m;
+}
+
 /* ls::line_search_error_checking, src/utils/line_search.cpp:86-153 */
 static void ls_error_checking(kt_t *k, kt_t *lsk, double *const *gram, ls_t *p) {
   for (int n = 0; n < k->n_modes; n++) {
@@ -827,6 +839,7 @@ static void ls_error_checking(kt_t *k, kt_t *lsk, double *const *gram, ls_t *p) 
   for (int64_t c = 0; c < k->rank; c++) lsk->lambda[c] = k->lambda[c];
   const double error = compute_error_slow(p->T, lsk);
   const double old_error = k->err;
+  ls_note_margin(k, error, old_error);
   p->reversed = 1;
   if (error < old_error) {
     p->reversed = 0;
@@ -847,6 +860,7 @@ static void line_search(kt_t *k, double *const *gram, ls_t *p) {
   if (p->method == OR_LS_NO_ERROR_CHECKING) {
     if (p->updated_last_iter) {
       p->updated_last_iter = 0;
+      ls_note_margin(k, p->backup.err, k->err);
       if (p->backup.err < k->err) {
         p->reversed = 1;
         p->iter = 0;

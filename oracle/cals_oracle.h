@@ -80,6 +80,10 @@ typedef struct {
   /* outputs */
   int64_t iters;
   double fit, old_fit, approx_error;
+  /* test instrumentation (no counterpart in the reference): the smallest relative distance |e1 - e2| / max(|e1|, |e2|)
+   * between the two errors of any accept / revert test of the line search (line_search.cpp:239, :116) this model went
+   * through; 1e300 = none.  Rounding-sized = that decision was a tie. */
+  double ls_margin;
 } or_model;
 
 void or_default_params(or_params *p);

@@ -41,7 +41,7 @@ class OrModel(C.Structure):
         ("rank", C.c_int64), ("factors", C.POINTER(C.c_double) * OR_MAX_MODES),
         ("lambda_", C.POINTER(C.c_double)), ("jk_enabled", C.c_int), ("jk_mode", C.c_int),
         ("jk_fiber", C.c_int64), ("iters", C.c_int64), ("fit", C.c_double),
-        ("old_fit", C.c_double), ("approx_error", C.c_double),
+        ("old_fit", C.c_double), ("approx_error", C.c_double), ("ls_margin", C.c_double),
     ]
 
 
@@ -246,6 +246,7 @@ class Model:
         self.jk = jk  # (mode, fiber) or None
         self.iters = 0
         self.fit = self.old_fit = self.error = 0.0
+        self.ls_margin = 1e300
 
     def copy(self):
         m = Model([f.copy(order="F") for f in self.factors], self.lam.copy(), self.jk)
@@ -262,6 +263,7 @@ class Model:
 
     def _read(self, om):
         self.iters, self.fit, self.old_fit, self.error = om.iters, om.fit, om.old_fit, om.approx_error
+        self.ls_margin = om.ls_margin
 
 
 def cp_als(X, modes, model, params):

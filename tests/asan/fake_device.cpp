@@ -318,6 +318,7 @@ hipError_t init_slots_launch(const int *desc, int n, const ModelTable &mt, hipSt
       mt.iters[slot] = 1;
       mt.err[slot] = mt.fit[slot] = mt.old_fit[slot] = 0.0;
       mt.potrf_info[slot] = mt.ls_iter[slot] = mt.ls_updated_last[slot] = mt.flags[slot] = 0;
+      mt.ls_margin[slot] = 1e300;
       if (g_admitted < g_schedule.size()) g_slot_target[slot] = g_schedule[g_admitted];
       g_admitted++;
     }
@@ -333,6 +334,7 @@ hipError_t ls_launch(const LsArgs &a, hipStream_t) {
       const int slot = a.slots[k];
       const bool hit = ((slot * 3 + a.mt.iters[slot]) % 5) == 0 && a.mt.iters[slot] < a.max_iter;
       a.mt.flags[slot] = hit ? 1 : 0;
+      if (hit) a.mt.ls_margin[slot] = 0.25;  // recognisable value for the host read-back
       if (hit && a.changed) *a.changed += a.mt.rank[slot];
     }
   });
@@ -382,6 +384,7 @@ hipError_t pack_status_launch(const int *slots, int n, const ModelTable &mt, con
       r.err = mt.err[slot];
       r.fit = mt.fit[slot];
       r.old_fit = mt.old_fit[slot];
+      r.ls_margin = mt.ls_margin[slot];
       out[1 + k] = r;
     }
   });

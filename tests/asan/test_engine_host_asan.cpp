@@ -104,6 +104,8 @@ static void c_abi_life_cycles(int dtype) {
       cals_hip_model_status st;
       CHECK(cals_hip_model_result(e, m.ticket, &st) == CALS_HIP_OK);
       CHECK(st.evicted == 1 && st.iters >= 1 && st.iters <= 25);
+      double margin = -1.0;  // the fake line search leaves 0.25 behind for every model it "extrapolated"
+      CHECK(cals_hip_debug_ls_margin(e, m.ticket, &margin) == CALS_HIP_OK && (margin == 1e300 || margin == 0.25));
       for (size_t n = 0; n < 3; n++)
         for (size_t i = 0; i < m.f[n].size(); i++) {
           const double want = dtype == CALS_HIP_F32 ? (double)(float)m.f0[n][i] : m.f0[n][i];

@@ -198,6 +198,8 @@ def test_c3_stale_column_patch_equals_dropping_T(cc, inputs):
             e.set_profiling(2)
             rep = e.run()
             ks = e.kernel_stats()
+            for m in gm:
+                m.ls_margin = e.ls_margin(m)
             e.close()
         finally:
             if env is not None:
@@ -225,7 +227,12 @@ def test_c3_stale_column_patch_equals_dropping_T(cc, inputs):
         worst = max(rel(fa, fb) for fa, fb in zip(a.factors, b.factors))
         if a.iters != b.iters or worst >= TOL_RUN:
             flipped += 1
+            # ... and every such model DID go through a tie: an accept / revert test whose two errors agree to 1e-9
+            # (cals_hip_debug_ls_margin; a model that never came near one and still ends elsewhere would be a defect)
+            assert min(a.ls_margin, b.ls_margin) <= 1e-9, (a.ls_margin, b.ls_margin, worst)
     assert flipped <= 20, flipped
+    print("patch vs drop: %d of %d models took the other side of a tie; smallest margin of the others %.1e" % (
+        flipped, len(gp), min(min(a.ls_margin, b.ls_margin) for a, b in zip(gp, gd))))
 
 
 def _c5_models(inputs, world=8, total=2048):

@@ -15,6 +15,7 @@ from test_gpu_parity import _assert_models_match, _run_both
 
 pytestmark = pytest.mark.gpu
 TOL_NNLS = 1e-8
+TIE = 1e-9  # relative distance of two errors below which an accept / revert test is a tie (rounding of a cancelled sum)
 NNLS = 1
 
 
@@ -112,6 +113,10 @@ def test_nnls_with_line_search_vs_oracle(cc, oracle, inputs, method):
     # its test compares two errors that are equal up to rounding (the device's reciprocal-multiply / rsq pivots move
     # them by an ulp); either outcome leaves the same factors, which _check verifies
     assert abs(rep.ls_failed - ro.ls_failed) <= 1
+    # ... and when one did, it WAS such a tie: some model went through a test whose two errors agree to rounding
+    # (cals_hip_debug_ls_margin: the smallest relative distance over the model's tests)
+    if rep.ls_failed != ro.ls_failed:
+        assert min(m.ls_margin for m in gm) <= TIE, [m.ls_margin for m in gm]
     # the last sweep may end on an extrapolated (unconstrained) state, as in the reference
     _check(gm, om, rep, ro, nonneg=False)
 

@@ -185,6 +185,8 @@ def _run_both(cc, oracle, inputs, modes, ranks, X, iters, jk=None, buffer=None, 
     prm = cc.default_params(max_iterations=iters, force_max_iter=force, **kw)
     e, gm, base = engine_with(cc, inputs, modes, ranks, X, jk=jk, buffer=buffer, params=prm)
     rep = e.run()
+    for m in gm:
+        m.ls_margin = e.ls_margin(m)  # how close to a tie the model's accept / revert tests were
     e.close()
     om = [oracle.Model(fs, lam, jk=j) for fs, lam, j in base]
     po = oracle.default_params(max_iterations=iters, force_max_iter=force, mttkrp_method=oracle.MTTKRP,
@@ -242,6 +244,27 @@ def test_line_search_vs_oracle(cc, oracle, inputs):
     assert (rep.ls_performed, rep.ls_failed) == (ro.ls_performed, ro.ls_failed)
     assert rep.ls_performed > 0
     _assert_models_match(gm, om, ro.X_norm ** 2)
+    _assert_margins_match(gm, om)
+
+
+def _assert_margins_match(gm, om):
+    """cals_hip_debug_ls_margin against the oracle's own record (or_model::ls_margin): the smallest relative distance
+    between the two errors of a model's accept / revert tests.  The errors are sqrt of a cancelled sum, so the distance
+    itself carries their rounding noise: compared absolutely at 1e-9 (the tie threshold the tolerant tests use)."""
+    tested = 0
+    for a, b in zip(gm, om):
+        if b.ls_margin >= 1e300:
+            assert a.ls_margin >= 1e300  # the model went through no test on either side
+            continue
+        tested += 1
+        assert 0.0 <= a.ls_margin <= 1.0 and abs(a.ls_margin - b.ls_margin) <= 1e-9, (a.ls_margin, b.ls_margin)
+    return tested
+
+
+def test_no_line_search_no_margin(cc, oracle, inputs):
+    modes, ranks = [13, 12, 11], [2, 5]
+    gm, om, rep, ro = _run_both(cc, oracle, inputs, modes, ranks, inputs.tensor(modes, 3), 6)
+    assert all(m.ls_margin == 1e300 for m in gm) and all(m.ls_margin == 1e300 for m in om)
 
 
 @pytest.mark.parametrize("method,interval,noise", [(1, 5, 0.1), (2, 3, 0.05), (1, 2, 0.3)])
@@ -262,6 +285,7 @@ def test_error_checking_line_search_vs_oracle(cc, oracle, inputs, method, interv
     else:
         assert rep.ls_performed == 0  # the reference never dispatches ERROR_CHECKING_PARALLEL
     _assert_models_match(gm, om, ro.X_norm ** 2)
+    assert (_assert_margins_match(gm, om) > 0) == (method == 1)
 
 
 @pytest.mark.parametrize("ls", [0, 1])
