@@ -27,6 +27,11 @@ namespace calship {
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 
+// 1: the backward row solve of update_body_lds runs without `< r` guards on the identity-padded L (bit-identical results;
+// C4 -5 us per sweep, C2 / C3 unchanged; the same for the forward solve spills 4 KB: not done)
+#ifndef CALS_UPD_BACK_NOGUARD
+#define CALS_UPD_BACK_NOGUARD 0
+#endif
 // update kernels: one workgroup of 4 waves per model
 #define UPD_THREADS 256
 #define UPD_WAVES 4
@@ -627,6 +632,17 @@ static __device__ UPD_BODY_ATTR void update_body_lds(UpdArgsPtr a_ptr, int slot,
         __syncthreads();  // barrier NPAN: 1 / diagonal is in LDS, the factorisation is through
         asm volatile("" ::: "memory");
       }
+#if CALS_UPD_BACK_NOGUARD
+      // L is diag(L_r, I) in LDS and x is zero in the padded columns (upd_load_g_row), 1 / diagonal is 1 there: the padded
+      // steps subtract exact zeros -- no `< r` guard, one basic block, and the compiler may take a column's entries of L
+      // (one contiguous run, read 16 bytes at a time) while the previous column's chain of FMAs is still running
+#pragma unroll
+      for (int j = RMAX - 1; j >= 0; --j) {
+#pragma unroll
+        for (int k = j + 1; k < RMAX; ++k) x[j] -= Hs[k + RMAX * j] * x[k];
+        x[j] = dinv[j] * x[j];
+      }
+#else
 #pragma unroll
       for (int j = RMAX - 1; j >= 0; --j) {
         if (j < r) {
@@ -636,6 +652,7 @@ static __device__ UPD_BODY_ATTR void update_body_lds(UpdArgsPtr a_ptr, int slot,
           x[j] = dinv[j] * x[j];
         }
       }
+#endif
     }
     if (i == jkf) {
 #pragma unroll

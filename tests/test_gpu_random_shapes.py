@@ -76,8 +76,8 @@ def test_random_shape_mttkrp_and_sweeps(cc, oracle, inputs, modes, ranks, plan, 
         for a, b in zip(gm, om):
             assert a.iters == b.iters
             if dtype == "f64":
-                for fa, fb in zip(a.factors, b.factors):
-                    assert rel(fa, fb) < rtol
+                for n, (fa, fb) in enumerate(zip(a.factors, b.factors)):
+                    assert rel(fa, fb) < rtol, (a.rank, n, rel(fa, fb), [int(np.isnan(f).sum()) for f in a.factors])
             else:
                 # fp32 storage: the fitted tensor, not the raw factors.  From a model's second sweep on a column is
                 # scaled by its entry of largest magnitude WITH ITS SIGN (Ktensor::normalize, ktensor.cpp:72-80); two
