@@ -277,6 +277,21 @@ static_assert(sizeof(double) * (16 * 17) <= sizeof(double) * CALS_RFAST * CALS_R
 // its kernel does, so it ends the wave itself (s_endpgm) -- a returning function would first reload the
 // callee-saved registers it saved on entry (47 scratch loads + a wait at rank 20) for a caller that ends at once.
 #define UPD_BODY_ATTR __attribute__((noinline, noreturn))
+// How a body ends its wave.  __builtin_amdgcn_endpgm() is a "return" to the frame lowering, which puts the reloads of all
+// callee-saved registers in front of it (75 scratch loads at rank 20 that nothing ever uses, and the wave is not retired
+// before they have come back); an s_endpgm the compiler does not see, followed by unreachable, leaves no return block.
+#ifndef CALS_UPD_ASM_ENDPGM
+#define CALS_UPD_ASM_ENDPGM 1
+#endif
+#if CALS_UPD_ASM_ENDPGM
+#define UPD_END_WAVE()               \
+  do {                               \
+    asm volatile("s_endpgm" ::: "memory"); \
+    __builtin_unreachable();         \
+  } while (0)
+#else
+#define UPD_END_WAVE() __builtin_amdgcn_endpgm()
+#endif
 template <int RMAX, typename T>
 static __device__ UPD_BODY_ATTR void update_body(UpdArgsPtr a_ptr, int slot, int r, int col, int jkp,
                                                       UpdShared &sh) {
@@ -555,7 +570,7 @@ static __device__ UPD_BODY_ATTR void update_body(UpdArgsPtr a_ptr, int slot, int
       if (a.fin.on) apply_finish_rule(a, slot);
     }
   }
-  __builtin_amdgcn_endpgm();  // the body ends the wave (see UPD_BODY_ATTR): no epilogue that reloads callee-saved registers
+  UPD_END_WAVE();  // the body ends the wave (see UPD_BODY_ATTR): no epilogue that reloads callee-saved registers
 }
 
 // The same update with the model's factor panel kept in LDS between the phases (used when
@@ -954,7 +969,7 @@ static __device__ UPD_BODY_ATTR void update_body_lds(UpdArgsPtr a_ptr, int slot,
       if (a.fin.on) apply_finish_rule(a, slot);
     }
   }
-  __builtin_amdgcn_endpgm();  // the body ends the wave (see UPD_BODY_ATTR): no epilogue that reloads callee-saved registers
+  UPD_END_WAVE();  // the body ends the wave (see UPD_BODY_ATTR): no epilogue that reloads callee-saved registers
 }
 
 __device__ __forceinline__ double lane_bcast(double v, int l) {  // l wave-uniform
@@ -1433,7 +1448,7 @@ static __device__ UPD_BODY_ATTR void update_body_huge(UpdArgsPtr a_ptr, int slot
       if (a.fin.on) apply_finish_rule(a, slot);
     }
   }
-  __builtin_amdgcn_endpgm();  // the body ends the wave (see UPD_BODY_ATTR): no epilogue that reloads callee-saved registers
+  UPD_END_WAVE();  // the body ends the wave (see UPD_BODY_ATTR): no epilogue that reloads callee-saved registers
 }
 
 // Three kernels, one per body class, each launched only when its class is in flight (update_launch); the
